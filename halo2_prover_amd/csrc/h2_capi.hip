@@ -1,0 +1,532 @@
+// h2_capi.hip -- implementation of include/h2hip.h (the drop-in C ABI).
+//
+// One context per process, bound to one GPU.  Every entry point validates its arguments,
+// takes the context mutex, enqueues on the context stream (or the caller's) and reports
+// errors as h2_status_t values: nothing throws or aborts across the ABI
+// (the reference's panics -- /root/reference/circuits/src/utils.rs:91,120 `.expect(..)`,
+// best_multiexp's assert_eq!(coeffs.len(), bases.len()) -- become H2_EINVAL here).
+#include "../../include/h2hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "h2_msm.hpp"
+#include "h2_ntt.hpp"
+
+using namespace h2;
+
+namespace {
+
+struct BasesEntry {
+  int curve;
+  size_t n;
+  MsmGeom geom;
+  void* table;  // W * n affine points
+  size_t table_bytes;
+};
+
+struct TwiddleEntry {
+  int field;
+  uint32_t log_n;
+  uint64_t omega[4];
+  void* tw;
+  uint64_t stamp;
+};
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  void* ws = nullptr;       // workspace arena (MSM scratch / NTT ping-pong)
+  size_t ws_bytes = 0;
+  void* stage = nullptr;    // device staging for host-pointer entry points
+  size_t stage_bytes = 0;
+  std::map<uint64_t, BasesEntry> bases;
+  uint64_t next_handle = 1;
+  std::vector<TwiddleEntry> twiddles;
+  uint64_t stamp = 0;
+  std::string last_error;
+};
+
+Context g_ctx;
+std::mutex g_mu;
+
+int dev_fail(hipError_t e, const char* where) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s: %s", where, hipGetErrorString(e));
+  g_ctx.last_error = buf;
+  return H2_EDEVICE;
+}
+#define H2_TRY(call)                                  \
+  do {                                                \
+    hipError_t _e = (call);                           \
+    if (_e != hipSuccess) return dev_fail(_e, #call); \
+  } while (0)
+
+int ensure_arena(void** p, size_t* have, size_t want) {
+  if (*have >= want) return H2_OK;
+  if (*p) {
+    // rare: a larger call than any before.  Work enqueued on caller streams may still use the arena.
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return dev_fail(e, "hipDeviceSynchronize");
+    (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+  }
+  size_t sz = want + (want >> 3);  // head-room so slightly larger calls do not reallocate
+  hipError_t e = hipMalloc(p, sz);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    g_ctx.last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return H2_ENOMEM;
+  }
+  *have = sz;
+  return H2_OK;
+}
+
+bool curve_ok(int c) { return c == H2_BN254 || c == H2_PALLAS || c == H2_VESTA; }
+
+template <class F>
+int dispatch(int curve, F&& f) {
+  switch (curve) {
+    case H2_BN254: return f(BN254_CURVE{});
+    case H2_PALLAS: return f(PALLAS_CURVE{});
+    case H2_VESTA: return f(VESTA_CURVE{});
+  }
+  return H2_EINVAL;
+}
+
+// ---- bases ---------------------------------------------------------------------------------
+int register_device(int curve, const void* d_affine, size_t n, uint64_t* handle_out) {
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok(curve) || !d_affine || !handle_out || n == 0) return H2_EINVAL;
+  return dispatch(curve, [&](auto cv) -> int {
+    using CV = decltype(cv);
+    MsmGeom g = msm_geometry(n, CV::Scalar::NUM_BITS);
+    if ((uint64_t)g.W * n >= (1ull << 31)) return H2_EINVAL;
+    BasesEntry be{};
+    be.curve = curve;
+    be.n = n;
+    be.geom = g;
+    be.table_bytes = (size_t)g.W * n * 64;
+    hipError_t e = hipMalloc(&be.table, be.table_bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      g_ctx.last_error = std::string("hipMalloc(table): ") + hipGetErrorString(e);
+      return H2_ENOMEM;
+    }
+    hipLaunchKernelGGL(msm_table_kernel<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_ctx.stream,
+                       (const U128*)d_affine, (U128*)be.table, (uint32_t)n, g);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
+    if (e != hipSuccess) {
+      (void)hipFree(be.table);
+      return dev_fail(e, "msm_table_kernel");
+    }
+    uint64_t h = g_ctx.next_handle++;
+    g_ctx.bases[h] = be;
+    *handle_out = h;
+    return H2_OK;
+  });
+}
+
+// ---- MSM -----------------------------------------------------------------------------------
+// enqueue; the m XYZZ results land at ws + off_tree2
+int msm_enqueue(int curve, const BasesEntry& be, const void* d_scalars, size_t n, size_t m, hipStream_t stream,
+                MsmWorkspace* ws_out) {
+  MsmWorkspace ws = msm_workspace(n, m, be.geom);
+  if (ws.E >= (1ull << 31) || ws.K >= (1ull << 31)) return H2_EINVAL;
+  int rc = ensure_arena(&g_ctx.ws, &g_ctx.ws_bytes, ws.total);
+  if (rc != H2_OK) return rc;
+  *ws_out = ws;
+  return dispatch(curve, [&](auto cv) -> int {
+    using CV = decltype(cv);
+    hipError_t e = msm_launch<CV>((const U128*)be.table, (uint32_t)be.n, (const U128*)d_scalars, n, m, be.geom,
+                                  (char*)g_ctx.ws, ws, stream);
+    if (e != hipSuccess) return dev_fail(e, "msm_launch");
+    return H2_OK;
+  });
+}
+
+int msm_common_checks(int curve, uint64_t handle, size_t n, size_t m, const BasesEntry** be) {
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok(curve) || m == 0) return H2_EINVAL;
+  auto it = g_ctx.bases.find(handle);
+  if (it == g_ctx.bases.end()) return H2_EHANDLE;
+  if (it->second.curve != curve) return H2_EINVAL;
+  if (n > it->second.n) return H2_EINVAL;  // best_multiexp: assert_eq!(coeffs.len(), bases.len())
+  *be = &it->second;
+  return H2_OK;
+}
+
+// ---- NTT -----------------------------------------------------------------------------------
+int scalar_field_of(int curve) {
+  switch (curve) {
+    case H2_BN254: return BN254_FR::ID;
+    case H2_PALLAS: return PASTA_FQ::ID;
+    case H2_VESTA: return PASTA_FP::ID;
+  }
+  return -1;
+}
+
+template <class FP>
+int get_twiddles(const uint64_t omega[4], uint32_t log_n, hipStream_t stream, const U128** out) {
+  for (auto& t : g_ctx.twiddles) {
+    if (t.field == FP::ID && t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) {
+      t.stamp = ++g_ctx.stamp;
+      *out = (const U128*)t.tw;
+      return H2_OK;
+    }
+  }
+  if (g_ctx.twiddles.size() >= 16) {  // evict the least recently used table
+    size_t victim = 0;
+    for (size_t i = 1; i < g_ctx.twiddles.size(); i++)
+      if (g_ctx.twiddles[i].stamp < g_ctx.twiddles[victim].stamp) victim = i;
+    H2_TRY(hipStreamSynchronize(g_ctx.stream));
+    (void)hipFree(g_ctx.twiddles[victim].tw);
+    g_ctx.twiddles.erase(g_ctx.twiddles.begin() + victim);
+  }
+  TwiddleEntry te{};
+  te.field = FP::ID;
+  te.log_n = log_n;
+  memcpy(te.omega, omega, 32);
+  const size_t bytes = (((size_t)1 << log_n) / 2) * 32;
+  hipError_t e = hipMalloc(&te.tw, bytes < 64 ? 64 : bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return H2_ENOMEM;
+  }
+  Fe<FP> w;
+  memcpy(w.v, omega, 32);
+  e = ntt_build_twiddles<FP>((U128*)te.tw, w, log_n, stream);
+  if (e != hipSuccess) {
+    (void)hipFree(te.tw);
+    return dev_fail(e, "ntt_build_twiddles");
+  }
+  te.stamp = ++g_ctx.stamp;
+  g_ctx.twiddles.push_back(te);
+  *out = (const U128*)te.tw;
+  return H2_OK;
+}
+
+template <class FP>
+int ntt_enqueue_t(void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream) {
+  const U128* tw = nullptr;
+  int rc = get_twiddles<FP>(omega, log_n, stream, &tw);
+  if (rc != H2_OK) return rc;
+  NttPlan pl = ntt_make_plan(log_n);
+  void* scratch = nullptr;
+  if (pl.npass > 1) {
+    rc = ensure_arena(&g_ctx.ws, &g_ctx.ws_bytes, m * ((size_t)32 << log_n));
+    if (rc != H2_OK) return rc;
+    scratch = g_ctx.ws;
+  }
+  hipError_t e = ntt_launch<FP>((U128*)d_a, (U128*)scratch, tw, log_n, m, stream);
+  if (e != hipSuccess) return dev_fail(e, "ntt_launch");
+  return H2_OK;
+}
+
+int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream) {
+  switch (curve) {
+    case H2_BN254: return ntt_enqueue_t<BN254_FR>(d_a, m, omega, log_n, stream);
+    case H2_PALLAS: return ntt_enqueue_t<PASTA_FQ>(d_a, m, omega, log_n, stream);
+    case H2_VESTA: return ntt_enqueue_t<PASTA_FP>(d_a, m, omega, log_n, stream);
+  }
+  return H2_EINVAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int h2_version(void) { return 1000; }
+
+const char* h2_strerror(int s) {
+  switch (s) {
+    case H2_OK: return "ok";
+    case H2_EINVAL: return "invalid argument (length / log_n mismatch, null pointer or unknown curve)";
+    case H2_ENOMEM: return "out of memory";
+    case H2_EDEVICE: return "HIP device error";
+    case H2_EHANDLE: return "unknown bases handle";
+    case H2_ENOTINIT: return "h2_init has not been called";
+  }
+  return "unknown status";
+}
+
+const char* h2_last_device_error(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  static thread_local std::string copy;
+  copy = g_ctx.last_error;
+  return copy.c_str();
+}
+
+int h2_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_ctx.ready) return g_ctx.device == device ? H2_OK : H2_EINVAL;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    (void)hipGetLastError();
+    g_ctx.last_error = "no HIP device available";
+    return H2_EDEVICE;
+  }
+  if (device < 0 || device >= count) return H2_EINVAL;
+  H2_TRY(hipSetDevice(device));
+  H2_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  g_ctx.device = device;
+  g_ctx.ready = true;
+  return H2_OK;
+}
+
+int h2_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_OK;
+  (void)hipStreamSynchronize(g_ctx.stream);
+  for (auto& kv : g_ctx.bases) (void)hipFree(kv.second.table);
+  g_ctx.bases.clear();
+  for (auto& t : g_ctx.twiddles) (void)hipFree(t.tw);
+  g_ctx.twiddles.clear();
+  if (g_ctx.ws) (void)hipFree(g_ctx.ws);
+  if (g_ctx.stage) (void)hipFree(g_ctx.stage);
+  g_ctx.ws = g_ctx.stage = nullptr;
+  g_ctx.ws_bytes = g_ctx.stage_bytes = 0;
+  (void)hipStreamDestroy(g_ctx.stream);
+  g_ctx.stream = nullptr;
+  g_ctx.ready = false;
+  g_ctx.device = -1;
+  return H2_OK;
+}
+
+int h2_bases_register_device(h2_curve_t curve, const void* d_affine, size_t n, uint64_t* handle_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return register_device((int)curve, d_affine, n, handle_out);
+}
+
+int h2_bases_register(h2_curve_t curve, const uint64_t* affine, size_t n, uint64_t* handle_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !affine || !handle_out || n == 0) return H2_EINVAL;
+  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, n * 64);
+  if (rc != H2_OK) return rc;
+  H2_TRY(hipMemcpyAsync(g_ctx.stage, affine, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
+  return register_device((int)curve, g_ctx.stage, n, handle_out);
+}
+
+int h2_bases_release(uint64_t handle) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  auto it = g_ctx.bases.find(handle);
+  if (it == g_ctx.bases.end()) return H2_EHANDLE;
+  (void)hipStreamSynchronize(g_ctx.stream);
+  (void)hipFree(it->second.table);
+  g_ctx.bases.erase(it);
+  return H2_OK;
+}
+
+int64_t h2_bases_len(uint64_t handle) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  auto it = g_ctx.bases.find(handle);
+  if (it == g_ctx.bases.end()) return H2_EHANDLE;
+  return (int64_t)it->second.n;
+}
+
+int h2_msm_plan(uint64_t handle, h2_msm_plan_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!out) return H2_EINVAL;
+  auto it = g_ctx.bases.find(handle);
+  if (it == g_ctx.bases.end()) return H2_EHANDLE;
+  out->window_bits = it->second.geom.c;
+  out->windows = it->second.geom.W;
+  out->buckets = it->second.geom.B;
+  out->table_bytes = it->second.table_bytes;
+  return H2_OK;
+}
+
+int h2_msm_device(h2_curve_t curve, uint64_t handle, const void* d_scalars, size_t n, size_t m, void* d_out_jac,
+                  void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const BasesEntry* be = nullptr;
+  int rc = msm_common_checks((int)curve, handle, n, m, &be);
+  if (rc != H2_OK) return rc;
+  if (!d_out_jac || (n && !d_scalars)) return H2_EINVAL;
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
+  if (n == 0) {
+    H2_TRY(hipMemsetAsync(d_out_jac, 0, m * 96, stream));
+    return H2_OK;
+  }
+  MsmWorkspace ws;
+  rc = msm_enqueue((int)curve, *be, d_scalars, n, m, stream, &ws);
+  if (rc != H2_OK) return rc;
+  return dispatch((int)curve, [&](auto cv) -> int {
+    using CV = decltype(cv);
+    hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, stream,
+                       (const U128*)((char*)g_ctx.ws + ws.off_tree2), (U128*)d_out_jac, (uint32_t)m);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dev_fail(e, "msm_to_jacobian_kernel");
+    return H2_OK;
+  });
+}
+
+static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* cols, size_t n, size_t m, uint64_t* out,
+                    bool affine_out) {
+  const BasesEntry* be = nullptr;
+  int rc = msm_common_checks((int)curve, handle, n, m, &be);
+  if (rc != H2_OK) return rc;
+  if (!out || !cols) return H2_EINVAL;
+  const size_t out_sz = affine_out ? 64 : 96;
+  if (n == 0) {
+    memset(out, 0, m * out_sz);
+    return H2_OK;
+  }
+  for (size_t j = 0; j < m; j++)
+    if (!cols[j]) return H2_EINVAL;
+  const size_t col_bytes = n * 32;
+  const size_t res_off = h2_align256(m * col_bytes);
+  rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, res_off + m * 96);
+  if (rc != H2_OK) return rc;
+  for (size_t j = 0; j < m; j++)
+    H2_TRY(hipMemcpyAsync((char*)g_ctx.stage + j * col_bytes, cols[j], col_bytes, hipMemcpyHostToDevice,
+                          g_ctx.stream));
+  MsmWorkspace ws;
+  rc = msm_enqueue((int)curve, *be, g_ctx.stage, n, m, g_ctx.stream, &ws);
+  if (rc != H2_OK) return rc;
+  void* d_res = (char*)g_ctx.stage + res_off;
+  rc = dispatch((int)curve, [&](auto cv) -> int {
+    using CV = decltype(cv);
+    const U128* src = (const U128*)((char*)g_ctx.ws + ws.off_tree2);
+    if (affine_out)
+      hipLaunchKernelGGL(msm_to_affine_kernel<CV>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, g_ctx.stream, src,
+                         (U128*)d_res, (uint32_t)m);
+    else
+      hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, g_ctx.stream, src,
+                         (U128*)d_res, (uint32_t)m);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
+    return H2_OK;
+  });
+  if (rc != H2_OK) return rc;
+  H2_TRY(hipMemcpyAsync(out, d_res, m * out_sz, hipMemcpyDeviceToHost, g_ctx.stream));
+  H2_TRY(hipStreamSynchronize(g_ctx.stream));
+  return H2_OK;
+}
+
+int h2_msm(h2_curve_t curve, uint64_t handle, const uint64_t* scalars, size_t n, uint64_t out_jac[12]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (n && !scalars) return H2_EINVAL;
+  const uint64_t* cols[1] = {scalars ? scalars : (const uint64_t*)out_jac};
+  return msm_host(curve, handle, cols, n, 1, out_jac, false);
+}
+
+int h2_msm_batch(h2_curve_t curve, uint64_t handle, const uint64_t* const* scalars, size_t n, size_t m,
+                 uint64_t* out_affine) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return msm_host(curve, handle, scalars, n, m, out_affine, true);
+}
+
+int h2_ntt_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !omega || m == 0 || log_n > 30) return H2_EINVAL;
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
+  if (log_n == 0) return H2_OK;
+  return ntt_enqueue((int)curve, d_a, m, omega, log_n, stream);
+}
+
+int h2_ntt_batch(h2_curve_t curve, uint64_t* const* cols, size_t m, const uint64_t omega[4], uint32_t log_n) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !cols || !omega || m == 0 || log_n > 30) return H2_EINVAL;
+  for (size_t j = 0; j < m; j++)
+    if (!cols[j]) return H2_EINVAL;
+  if (log_n == 0) return H2_OK;
+  const size_t col_bytes = (size_t)32 << log_n;
+  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, m * col_bytes);
+  if (rc != H2_OK) return rc;
+  for (size_t j = 0; j < m; j++)
+    H2_TRY(hipMemcpyAsync((char*)g_ctx.stage + j * col_bytes, cols[j], col_bytes, hipMemcpyHostToDevice,
+                          g_ctx.stream));
+  rc = ntt_enqueue((int)curve, g_ctx.stage, m, omega, log_n, g_ctx.stream);
+  if (rc != H2_OK) return rc;
+  for (size_t j = 0; j < m; j++)
+    H2_TRY(hipMemcpyAsync(cols[j], (char*)g_ctx.stage + j * col_bytes, col_bytes, hipMemcpyDeviceToHost,
+                          g_ctx.stream));
+  H2_TRY(hipStreamSynchronize(g_ctx.stream));
+  return H2_OK;
+}
+
+int h2_ntt(h2_curve_t curve, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+  uint64_t* cols[1] = {a};
+  return h2_ntt_batch(curve, cols, 1, omega, log_n);
+}
+
+}  // extern "C"
+
+// ---- host self-test hooks (include/h2hip_selftest.h) ------------------------------------------
+#include "../../include/h2hip_selftest.h"
+namespace {
+template <class FP>
+int selftest_field(int op, const uint64_t* a_, const uint64_t* b_, uint64_t* out) {
+  Fe<FP> a, b, r;
+  memcpy(a.v, a_, 32);
+  memcpy(b.v, b_, 32);
+  switch (op) {
+    case 0: r = fe_add(a, b); break;
+    case 1: r = fe_sub(a, b); break;
+    case 2: r = fe_mul(a, b); break;
+    case 3: r = fe_inv(a); break;
+    case 4: r = fe_to_mont(a); break;
+    case 5: r = fe_from_mont(a); break;
+    case 6: r = fe_neg(a); break;
+    default: return H2_EINVAL;
+  }
+  memcpy(out, r.v, 32);
+  return H2_OK;
+}
+template <class CV>
+int selftest_curve(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out) {
+  Affine<CV> p, q;
+  memcpy(p.x.v, p_, 32); memcpy(p.y.v, p_ + 4, 32);
+  memcpy(q.x.v, q_, 32); memcpy(q.y.v, q_ + 4, 32);
+  Xyzz<CV> r;
+  switch (op) {
+    case 0: r = xyzz_add_affine(xyzz_from_affine(p), q); break;
+    case 1: r = xyzz_double_affine(p); break;
+    case 2: r = xyzz_add(xyzz_add_affine(xyzz_from_affine(p), q), xyzz_from_affine(q)); break;
+    case 3: {
+      uint32_t k = (uint32_t)q_[0];
+      r = Xyzz<CV>::identity();
+      Xyzz<CV> base = xyzz_from_affine(p);
+      for (int bit = 31; bit >= 0; bit--) {
+        r = xyzz_double(r);
+        if ((k >> bit) & 1) r = xyzz_add(r, base);
+      }
+      break;
+    }
+    default: return H2_EINVAL;
+  }
+  Affine<CV> a = xyzz_to_affine(r);
+  memcpy(out, a.x.v, 32);
+  memcpy(out + 4, a.y.v, 32);
+  return H2_OK;
+}
+}  // namespace
+extern "C" int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+  if (!a || !b || !out) return H2_EINVAL;
+  switch (field) {
+    case 0: return selftest_field<BN254_FQ>(op, a, b, out);
+    case 1: return selftest_field<BN254_FR>(op, a, b, out);
+    case 2: return selftest_field<PASTA_FP>(op, a, b, out);
+    case 3: return selftest_field<PASTA_FQ>(op, a, b, out);
+  }
+  return H2_EINVAL;
+}
+extern "C" int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]) {
+  if (!p || !q || !out) return H2_EINVAL;
+  return dispatch(curve, [&](auto cv) -> int { return selftest_curve<decltype(cv)>(op, p, q, out); });
+}

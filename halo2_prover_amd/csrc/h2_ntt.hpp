@@ -1,0 +1,273 @@
+// h2_ntt.hpp -- radix-2 NTT over 256-bit Montgomery fields for gfx950.
+//
+// Device replacement for halo2_proofs::arithmetic::best_fft / recursive_butterfly_arithmetic
+// (halo2_proofs @6b43b6b, src/arithmetic.rs -- un-vendored; algorithm restated in SURVEY.md
+// App. A.2; reached from /root/reference/circuits/src/utils.rs:83-91,105-120 through
+// EvaluationDomain::{lagrange_to_coeff, coeff_to_extended, extended_to_coeff}).
+// Contract kept: in place, natural order in and out, A[k] = sum_j a[j] w^(jk), unscaled.
+//
+// Structure (MI355X-first, not the reference's recursion): n = R1 * R2 * R3 with every radix
+// <= 2^10.  Each pass stages a tile of R x C elements in LDS (C consecutive "columns" so that
+// every HBM access is a run of C*32 contiguous bytes), runs the log2(R) butterfly stages out
+// of LDS with the R/2 twiddles of that radix also held in LDS, applies the inter-pass
+// twiddle w^(outer*i*k) and writes the tile back.  The last pass writes the digit-reversed
+// position directly, so no bit-reversal sweep over HBM is needed.  Per pass the algorithmic
+// HBM traffic is one read and one write of the column (64 B per element).
+#pragma once
+#include "h2_field.hpp"
+
+namespace h2 {
+
+struct NttPass {
+  uint32_t log_n;      // size of the whole transform
+  uint32_t log_outer;  // log2 of the product of the radices of earlier passes
+  uint32_t log_r;      // radix of this pass
+  uint32_t log_inner;  // log_n - log_outer - log_r
+  uint32_t log_c;      // tile columns
+  uint32_t log_r1;     // radix of pass 0 (0 when this is the only pass)
+  uint32_t log_r2;     // radix of pass 1 when there are three passes, else 0
+  uint32_t is_final;
+};
+
+__device__ __forceinline__ uint32_t h2_bitrev(uint32_t x, uint32_t bits) {
+  return bits ? (__brev(x) >> (32 - bits)) : 0;
+}
+
+// tw[i] = omega^i for i < half_n.  One thread fills TW_RUN consecutive entries.
+constexpr int TW_RUN = 16;
+template <class FP>
+__global__ void __launch_bounds__(256) ntt_twiddle_kernel(U128* tw, Fe<FP> omega, uint32_t half_n) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t start = (uint64_t)t * TW_RUN;
+  if (start >= half_n) return;
+  Fe<FP> cur = fe_pow_u64(omega, start);
+  for (int k = 0; k < TW_RUN && start + k < half_n; k++) {
+    fe_store<FP>(tw + 2 * (start + k), cur);
+    cur = fe_mul(cur, omega);
+  }
+}
+
+// One pass.  grid.x = tiles per column, grid.y = batch column.  Dynamic LDS:
+// (R*C + R/2) elements in two 16-byte planes (plane h holds limbs 4h..4h+3 of every element),
+// so a wave's ds_read_b128 / ds_write_b128 of consecutive elements is conflict-free.
+template <class FP>
+__global__ void __launch_bounds__(1024)
+ntt_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U128* __restrict__ tw, NttPass P,
+                size_t col_stride /* elements */) {
+  extern __shared__ U128 lds[];
+  const uint32_t R = 1u << P.log_r, C = 1u << P.log_c;
+  const uint32_t RC = R * C;
+  const uint32_t n_half_log = P.log_n - 1;
+  U128* tile0 = lds;             // plane 0 of the tile
+  U128* tile1 = lds + RC;        // plane 1
+  U128* twl0 = lds + 2 * RC;     // plane 0 of the radix twiddles
+  U128* twl1 = twl0 + (R >> 1);  // plane 1
+
+  const U128* src = in + 2 * col_stride * blockIdx.y;
+  U128* dst = out + 2 * col_stride * blockIdx.y;
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t tile = blockIdx.x;
+
+  // tile coordinates
+  uint64_t in_base;        // element address of (j = 0, cc = 0)
+  uint64_t in_j_stride;    // element stride between consecutive j
+  uint64_t in_c_stride;    // element stride between consecutive cc
+  uint32_t i_first = 0;    // inner index of cc = 0 (non-final passes)
+  uint64_t out_base, out_k_stride, out_c_stride;
+  if (!P.is_final) {
+    const uint32_t chunks = 1u << (P.log_inner - P.log_c);
+    const uint32_t ic = tile & (chunks - 1), o = tile >> (P.log_inner - P.log_c);
+    i_first = ic << P.log_c;
+    in_base = ((uint64_t)o << (P.log_r + P.log_inner)) + i_first;
+    in_j_stride = (uint64_t)1 << P.log_inner;
+    in_c_stride = 1;
+    out_base = in_base; out_k_stride = in_j_stride; out_c_stride = 1;
+  } else {
+    // C consecutive k1 (same k2); each row is R contiguous elements
+    const uint32_t groups_log = P.log_r1 - P.log_c;  // log2(R1 / C)
+    const uint32_t k1c = tile & ((1u << groups_log) - 1), k2 = tile >> groups_log;
+    const uint32_t k1 = k1c << P.log_c;
+    in_base = (((uint64_t)k1 << P.log_r2) + k2) << P.log_r;
+    in_j_stride = 1;
+    in_c_stride = (uint64_t)1 << (P.log_r2 + P.log_r);
+    out_base = (uint64_t)k1 + ((uint64_t)k2 << P.log_r1);
+    out_k_stride = (uint64_t)1 << (P.log_r1 + P.log_r2);
+    out_c_stride = 1;
+  }
+
+  // radix twiddles w_R^i = w^(i * n/R), i < R/2
+  for (uint32_t i = tid; i < (R >> 1); i += nthr) {
+    const U128* t = tw + 2 * ((uint64_t)i << (P.log_n - P.log_r));
+    twl0[i] = t[0];
+    twl1[i] = t[1];
+  }
+  // load the tile, bit-reversing j on the way in
+  if (!P.is_final) {
+    for (uint32_t e = tid; e < RC; e += nthr) {
+      const uint32_t cc = e & (C - 1), j = e >> P.log_c;
+      const U128* g = src + 2 * (in_base + (uint64_t)j * in_j_stride + cc);
+      const uint32_t l = (h2_bitrev(j, P.log_r) << P.log_c) + cc;
+      tile0[l] = g[0];
+      tile1[l] = g[1];
+    }
+  } else {
+    for (uint32_t e = tid; e < RC; e += nthr) {
+      const uint32_t j = e & (R - 1), cc = e >> P.log_r;
+      const U128* g = src + 2 * (in_base + (uint64_t)cc * in_c_stride + j);
+      const uint32_t l = (h2_bitrev(j, P.log_r) << P.log_c) + cc;
+      tile0[l] = g[0];
+      tile1[l] = g[1];
+    }
+  }
+  __syncthreads();
+
+  // butterfly stages
+  const uint32_t nbf = RC >> 1;
+  for (uint32_t s = 0; s < P.log_r; s++) {
+    const uint32_t half = 1u << s;
+    for (uint32_t w = tid; w < nbf; w += nthr) {
+      const uint32_t cc = w & (C - 1), b = w >> P.log_c;
+      const uint32_t pos = b & (half - 1), grp = b >> s;
+      const uint32_t i0 = (((grp << (s + 1)) + pos) << P.log_c) + cc;
+      const uint32_t i1 = i0 + (half << P.log_c);
+      Fe<FP> x, y;
+      {
+        U128 a0 = tile0[i0], a1 = tile1[i0], b0 = tile0[i1], b1 = tile1[i1];
+        x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w;
+        x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
+        y.v[0] = b0.x; y.v[1] = b0.y; y.v[2] = b0.z; y.v[3] = b0.w;
+        y.v[4] = b1.x; y.v[5] = b1.y; y.v[6] = b1.z; y.v[7] = b1.w;
+      }
+      if (pos != 0) {
+        const uint32_t ti = pos << (P.log_r - 1 - s);
+        U128 t0 = twl0[ti], t1 = twl1[ti];
+        Fe<FP> t;
+        t.v[0] = t0.x; t.v[1] = t0.y; t.v[2] = t0.z; t.v[3] = t0.w;
+        t.v[4] = t1.x; t.v[5] = t1.y; t.v[6] = t1.z; t.v[7] = t1.w;
+        y = fe_mul(y, t);
+      }
+      Fe<FP> u = fe_add(x, y), v = fe_sub(x, y);
+      tile0[i0] = U128{u.v[0], u.v[1], u.v[2], u.v[3]};
+      tile1[i0] = U128{u.v[4], u.v[5], u.v[6], u.v[7]};
+      tile0[i1] = U128{v.v[0], v.v[1], v.v[2], v.v[3]};
+      tile1[i1] = U128{v.v[4], v.v[5], v.v[6], v.v[7]};
+    }
+    __syncthreads();
+  }
+
+  // write back (with the inter-pass twiddle w^(outer * i * k) on non-final passes)
+  for (uint32_t e = tid; e < RC; e += nthr) {
+    const uint32_t cc = e & (C - 1), k = e >> P.log_c;
+    U128 a0 = tile0[e], a1 = tile1[e];
+    if (!P.is_final) {
+      const uint64_t ex = ((uint64_t)(i_first + cc) * k) << P.log_outer;  // < n
+      if (ex != 0) {
+        Fe<FP> x;
+        x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w;
+        x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
+        const uint64_t half_n = (uint64_t)1 << n_half_log;
+        const bool negate = ex >= half_n;
+        const uint64_t ti = negate ? ex - half_n : ex;
+        Fe<FP> t = fe_load<FP>(tw + 2 * ti);
+        x = fe_mul(x, t);
+        if (negate) x = fe_neg(x);
+        a0 = U128{x.v[0], x.v[1], x.v[2], x.v[3]};
+        a1 = U128{x.v[4], x.v[5], x.v[6], x.v[7]};
+      }
+    }
+    U128* g = dst + 2 * (out_base + (uint64_t)k * out_k_stride + (uint64_t)cc * out_c_stride);
+    g[0] = a0;
+    g[1] = a1;
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+struct NttPlan {
+  int npass;
+  NttPass pass[3];
+  uint32_t threads[3];
+  size_t lds_bytes[3];
+  uint32_t tiles[3];
+};
+
+constexpr uint32_t NTT_MAX_LOG_R = 10;  // R <= 1024: tile R*4 elements = 128 KiB + 16 KiB twiddles
+
+inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R, uint32_t want_log_c = 2) {
+  NttPlan pl{};
+  uint32_t np = log_n == 0 ? 1 : (log_n + max_log_r - 1) / max_log_r;
+  if (np > 3) np = 3;  // callers reject log_n > 30
+  uint32_t radix[3] = {0, 0, 0};
+  uint32_t left = log_n;
+  for (uint32_t p = 0; p < np; p++) {
+    radix[p] = (left + (np - p) - 1) / (np - p);
+    left -= radix[p];
+  }
+  pl.npass = (int)np;
+  uint32_t outer = 0;
+  for (uint32_t p = 0; p < np; p++) {
+    NttPass& P = pl.pass[p];
+    P.log_n = log_n;
+    P.log_outer = outer;
+    P.log_r = radix[p];
+    P.log_inner = log_n - outer - radix[p];
+    P.is_final = (p == np - 1);
+    P.log_r1 = np >= 2 ? radix[0] : 0;
+    P.log_r2 = np == 3 ? radix[1] : 0;
+    uint32_t lc = want_log_c;
+    if (P.is_final) {
+      if (lc > P.log_r1) lc = P.log_r1;
+    } else {
+      if (lc > P.log_inner) lc = P.log_inner;
+    }
+    P.log_c = lc;
+    const uint32_t rc = 1u << (P.log_r + lc);
+    pl.lds_bytes[p] = ((size_t)rc + ((size_t)1 << P.log_r) / 2) * 32;
+    if (pl.lds_bytes[p] < 64) pl.lds_bytes[p] = 64;
+    uint32_t thr = rc / 2;
+    if (thr < 64) thr = 64;
+    if (thr > 1024) thr = 1024;
+    pl.threads[p] = thr;
+    pl.tiles[p] = 1u << (log_n - P.log_r - lc);
+    outer += radix[p];
+  }
+  return pl;
+}
+
+// Enqueue the transform of m columns (column stride = n elements) on `stream`.
+// data: in place; scratch: m*n elements when the plan has more than one pass.
+template <class FP>
+inline hipError_t ntt_launch(U128* data, U128* scratch, const U128* tw, uint32_t log_n, size_t m,
+                             hipStream_t stream) {
+  if (log_n == 0 || m == 0) return hipSuccess;
+  NttPlan pl = ntt_make_plan(log_n);
+  const size_t n = (size_t)1 << log_n;
+  for (int p = 0; p < pl.npass; p++) {
+    const U128* src;
+    U128* dst;
+    if (pl.npass == 1) { src = data; dst = data; }
+    else if (p == 0) { src = data; dst = scratch; }
+    else if (p == pl.npass - 1) { src = scratch; dst = data; }
+    else { src = scratch; dst = scratch; }
+    dim3 grid(pl.tiles[p], (unsigned)m);
+    hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<FP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ntt_pass_kernel<FP>, grid, dim3(pl.threads[p]), pl.lds_bytes[p], stream, src, dst, tw,
+                       pl.pass[p], n);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <class FP>
+inline hipError_t ntt_build_twiddles(U128* tw, const Fe<FP>& omega, uint32_t log_n, hipStream_t stream) {
+  if (log_n == 0) return hipSuccess;
+  const uint32_t half_n = 1u << (log_n - 1);
+  const uint32_t threads = (half_n + TW_RUN - 1) / TW_RUN;
+  const uint32_t blocks = (threads + 255) / 256;
+  hipLaunchKernelGGL(ntt_twiddle_kernel<FP>, dim3(blocks), dim3(256), 0, stream, tw, omega, half_n);
+  return hipGetLastError();
+}
+
+}  // namespace h2

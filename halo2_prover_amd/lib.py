@@ -1,0 +1,85 @@
+"""ctypes loader for the C-ABI library (include/h2hip.h).
+
+The product path has no CPU fallback: if libh2hip.so is missing or cannot be loaded this
+module raises, and every compute entry point returns an error status without a GPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libh2hip.so")
+
+H2_BN254, H2_PALLAS, H2_VESTA = 0, 1, 2
+CURVES = {"bn254": H2_BN254, "pallas": H2_PALLAS, "vesta": H2_VESTA}
+
+H2_OK = 0
+STATUS_NAMES = {0: "H2_OK", -1: "H2_EINVAL", -2: "H2_ENOMEM", -3: "H2_EDEVICE", -4: "H2_EHANDLE", -5: "H2_ENOTINIT"}
+
+# every symbol include/h2hip.h declares: name -> (restype, argtypes)
+_P, _Z, _I, _U32, _U64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
+
+
+class MsmPlan(ctypes.Structure):
+    _fields_ = [("window_bits", _U32), ("windows", _U32), ("buckets", _U32), ("table_bytes", _U64)]
+
+
+SYMBOLS = {
+    "h2_init": (_I, [_I]),
+    "h2_shutdown": (_I, []),
+    "h2_strerror": (ctypes.c_char_p, [_I]),
+    "h2_last_device_error": (ctypes.c_char_p, []),
+    "h2_version": (_I, []),
+    "h2_bases_register": (_I, [_I, _P, _Z, ctypes.POINTER(_U64)]),
+    "h2_bases_register_device": (_I, [_I, _P, _Z, ctypes.POINTER(_U64)]),
+    "h2_bases_release": (_I, [_U64]),
+    "h2_bases_len": (ctypes.c_int64, [_U64]),
+    "h2_msm": (_I, [_I, _U64, _P, _Z, _P]),
+    "h2_msm_batch": (_I, [_I, _U64, _P, _Z, _Z, _P]),
+    "h2_msm_device": (_I, [_I, _U64, _P, _Z, _Z, _P, _P]),
+    "h2_ntt": (_I, [_I, _P, _P, _U32]),
+    "h2_ntt_batch": (_I, [_I, _P, _Z, _P, _U32]),
+    "h2_ntt_device": (_I, [_I, _P, _Z, _P, _U32, _P]),
+    "h2_msm_plan": (_I, [_U64, ctypes.POINTER(MsmPlan)]),
+}
+# include/h2hip_selftest.h (host instantiation of the device templates; not a compute path)
+SELFTEST_SYMBOLS = {
+    "h2_selftest_field_op": (_I, [_I, _I, _P, _P, _P]),
+    "h2_selftest_curve_op": (_I, [_I, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class H2Error(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        detail = ""
+        try:
+            msg = load().h2_strerror(status).decode()
+            dev = load().h2_last_device_error().decode()
+            detail = msg + (" [" + dev + "]" if dev and status == -3 else "")
+        except Exception:  # pragma: no cover
+            pass
+        super().__init__("%s failed: %s (%s)" % (where, STATUS_NAMES.get(status, status), detail))
+
+
+def load():
+    """Load libh2hip.so; raises (never falls back) when the HIP extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "halo2_prover_amd: %s not found -- build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in list(SYMBOLS.items()) + list(SELFTEST_SYMBOLS.items()):
+            fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, where):
+    if status != H2_OK:
+        raise H2Error(status, where)

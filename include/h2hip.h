@@ -1,0 +1,110 @@
+/*
+ * h2hip.h -- C ABI of the MI355X (gfx950) MSM / NTT backend for halo2.
+ *
+ * Drop-in boundary for the hot path of 0xWOLAND/halo2-prover: the calls
+ * halo2_proofs::plonk::create_proof / keygen_{vk,pk} make into
+ *   halo2_proofs::arithmetic::best_multiexp   (via ParamsKZG::commit / commit_lagrange)
+ *   halo2_proofs::arithmetic::best_fft        (via EvaluationDomain::{lagrange_to_coeff,
+ *                                              coeff_to_extended, extended_to_coeff})
+ * when driven by the reference's circuits/ crate:
+ *   /root/reference/circuits/src/utils.rs:63-70   (keygen)        -> fixed/sigma commitments
+ *   /root/reference/circuits/src/utils.rs:83-91   (SHPLONK prove) -> create_proof
+ *   /root/reference/circuits/src/utils.rs:105-120 (GWC prove)     -> create_proof
+ *   /root/reference/circuits/src/wasm.rs:57-65,77-122             -> same, behind wasm-bindgen
+ * The functions themselves live in the un-vendored dependency halo2_proofs @6b43b6b
+ * (circuits/Cargo.toml:16-17, Cargo.lock:836-838); their Rust signatures are restated in
+ * SURVEY.md section 8(b).  INTEGRATION.md shows the Rust-side `extern "C"` binding.
+ *
+ * Conventions (identical to halo2curves' in-memory layout, so a Rust slice can be passed as is):
+ *   field element  = 4 x u64 little-endian limbs, Montgomery form (R = 2^256)      32 bytes
+ *   affine point   = x || y, identity = (0, 0)                                     64 bytes
+ *   Jacobian point = x || y || z, identity has z = 0                               96 bytes
+ * All functions return 0 on success or a negative h2_status_t; they never abort or throw
+ * across the ABI (the reference panics on length mismatch; here that is H2_EINVAL).
+ * Calls are thread-safe and serialise on the device's internal stream.  One process drives
+ * one GPU (h2_init(device)); multi-GPU column sharding is done by the host layer over
+ * torch.distributed/RCCL, one rank per GPU.
+ */
+#ifndef H2HIP_H
+#define H2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { H2_BN254 = 0, H2_PALLAS = 1, H2_VESTA = 2 } h2_curve_t;
+
+typedef enum {
+  H2_OK = 0,
+  H2_EINVAL = -1,   /* bad argument: length / log_n mismatch, null pointer, unknown curve */
+  H2_ENOMEM = -2,   /* host or device allocation failed */
+  H2_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
+  H2_EHANDLE = -4,  /* unknown or released bases handle */
+  H2_ENOTINIT = -5  /* h2_init has not been called */
+} h2_status_t;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+/* Bind this process to one GPU (HIP device ordinal).  Idempotent for the same device. */
+int h2_init(int device);
+int h2_shutdown(void);
+const char* h2_strerror(int status);
+/* Text of the last HIP error seen by this process ("" if none). */
+const char* h2_last_device_error(void);
+/* ABI version: major * 1000 + minor. */
+int h2_version(void);
+
+/* ---- bases (the SRS: ParamsKZG::g / g_lagrange) ------------------------------------------
+ * Registers n affine points and keeps them -- plus the table of their 2^(c*w) multiples that
+ * lets every Pippenger window share one bucket set -- resident in HBM.  Replaces the `bases`
+ * slice argument of best_multiexp for all later calls (ParamsKZG::commit_lagrange passes
+ * g_lagrange, ParamsKZG::commit passes g).  `affine` is a host pointer. */
+int h2_bases_register(h2_curve_t curve, const uint64_t* affine /* n*8 */, size_t n, uint64_t* handle_out);
+/* Same, from a device pointer (the points are copied; the caller keeps ownership). */
+int h2_bases_register_device(h2_curve_t curve, const void* d_affine, size_t n, uint64_t* handle_out);
+int h2_bases_release(uint64_t handle);
+/* Number of points registered under the handle, or a negative status. */
+int64_t h2_bases_len(uint64_t handle);
+
+/* ---- MSM == best_multiexp(coeffs, bases) -> C::Curve ------------------------------------
+ * out_jac receives sum_i scalars[i] * bases[i] as a Jacobian point (any representative of
+ * the group element; compare after normalisation).  n may be smaller than the registered
+ * length (a prefix of the bases is used), never larger. */
+int h2_msm(h2_curve_t curve, uint64_t bases_handle, const uint64_t* scalars /* n*4 */, size_t n,
+           uint64_t out_jac[12]);
+/* m columns against the same bases (the per-column commitments of one proof phase).
+ * out_affine receives m normalised affine points (identity = (0,0)), column order. */
+int h2_msm_batch(h2_curve_t curve, uint64_t bases_handle, const uint64_t* const* scalars /* m ptrs */,
+                 size_t n, size_t m, uint64_t* out_affine /* m*8 */);
+/* Device-resident form: d_scalars holds m columns of n scalars, column stride n*32 bytes;
+ * d_out_jac receives m Jacobian points (m*96 bytes, device memory).  Enqueued on `stream`
+ * (a hipStream_t, NULL = the library's stream); returns without synchronising. */
+int h2_msm_device(h2_curve_t curve, uint64_t bases_handle, const void* d_scalars, size_t n, size_t m,
+                  void* d_out_jac, void* stream);
+
+/* ---- NTT == best_fft(a, omega, log_n) ---------------------------------------------------
+ * In place, natural order in and out, A[i] = sum_j a[j] * omega^(i*j), unscaled, over the
+ * SCALAR field of `curve` (bn256::Fr for H2_BN254).  a must hold exactly 1 << log_n elements. */
+int h2_ntt(h2_curve_t curve, uint64_t* a /* n*4, in place */, const uint64_t omega[4], uint32_t log_n);
+int h2_ntt_batch(h2_curve_t curve, uint64_t* const* cols /* m ptrs */, size_t m, const uint64_t omega[4],
+                 uint32_t log_n);
+/* Device-resident form: m columns, column stride (1 << log_n) * 32 bytes, in place. */
+int h2_ntt_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n,
+                  void* stream);
+
+/* ---- introspection used by bench.py's roofline (no effect on results) --------------------
+ * Names the kernels launched by the last h2_msm* / h2_ntt* call and their geometry. */
+typedef struct {
+  uint32_t window_bits;   /* c */
+  uint32_t windows;       /* W */
+  uint32_t buckets;       /* 2^(c-1) */
+  uint64_t table_bytes;   /* resident precomputed table */
+} h2_msm_plan_t;
+int h2_msm_plan(uint64_t bases_handle, h2_msm_plan_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2HIP_H */

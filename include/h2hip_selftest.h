@@ -1,0 +1,25 @@
+/*
+ * h2hip_selftest.h -- host-side self-test hooks of libh2hip.so (not part of the drop-in ABI).
+ *
+ * The field / curve templates in halo2_prover_amd/csrc are __host__ __device__; these entry
+ * points run the HOST instantiation of exactly that source so that `pytest -m "not gpu"` can
+ * compare it with the CPU oracle on a machine without a GPU.  They are not a compute path:
+ * one element per call, no batching, never used by the library itself.
+ */
+#ifndef H2HIP_SELFTEST_H
+#define H2HIP_SELFTEST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* field: 0 bn254_fq, 1 bn254_fr, 2 pasta_fp, 3 pasta_fq; op: 0 add, 1 sub, 2 mul, 3 inv, 4 to_mont,
+ * 5 from_mont, 6 neg.  Operands / result: 4 x u64 Montgomery limbs. */
+int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+/* curve ops on the host instantiation of the XYZZ formulas.  op: 0 = affine p + affine q,
+ * 1 = 2 * affine p, 2 = (p + q) + q via xyzz_add of two accumulators, 3 = [k] p (k < 2^32, in q[0])
+ * by double-and-add.  p, q: affine (8 limbs); out: affine (8 limbs), identity = zeros. */
+int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -85,7 +85,7 @@ def best_multiexp(cid, coeffs, bases, threads=1):
 
 
 def best_fft(fid, a, omega, log_n, threads=1):
-    a = _u64(a).copy()
+    a = _u64(a).reshape(-1).copy()
     omega = _u64(omega)
     assert a.size == 4 << log_n
     assert lib().h2o_best_fft(fid, _p(a), _p(omega), log_n, threads) == 0

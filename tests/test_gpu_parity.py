@@ -1,0 +1,216 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle, bit for bit.
+
+MSM results are group elements, so they are compared after affine normalisation (Jacobian
+representatives are not unique); NTT output is unique and compared bytewise
+(SURVEY.md section 8(b)).  BN254 is the curve the reference proves over (pinned oracle);
+Pallas/Vesta curve results are "parity unpinned" in the reference -- the oracle they are
+compared with is pinned only through its field arithmetic (tests/test_oracle_pins.py).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["bn254", "pallas", "vesta"]
+CID = O.CURVE_IDS
+SEED = 0x48324D5300000000
+
+
+def scalar_field(curve):
+    return R.CURVES[curve].scalar
+
+
+def omega_limbs(curve, log_n, inverse=False):
+    f = scalar_field(curve)
+    w = f.omega(log_n)
+    if inverse:
+        w = pow(w, -1, f.p)
+    return np.array(f.limbs(w), dtype=np.uint64)
+
+
+def rand_scalars(curve, n, seed=1):
+    return O.synth_scalars(O.CURVE_SCALAR_FIELD[CID[curve]], SEED | seed, n).reshape(n, 4)
+
+
+def rand_bases(curve, n, seed=0xB5):
+    return O.synth_bases(CID[curve], SEED | seed, n).reshape(n, 8)
+
+
+def norm(curve, jac):
+    return O.to_affine(CID[curve], np.asarray(jac, dtype=np.uint64).reshape(-1))
+
+
+# ------------------------------------------------------------------------------- NTT ----
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 7, 10, 11, 12, 13, 14, 16])
+def test_ntt_matches_oracle(h2, curve, log_n):
+    n = 1 << log_n
+    a = rand_scalars(curve, n, seed=log_n)
+    w = omega_limbs(curve, log_n)
+    want = O.best_fft(O.CURVE_SCALAR_FIELD[CID[curve]], a, w, log_n, threads=4).reshape(n, 4)
+    got = a.copy()
+    h2.best_fft(got, w, log_n, curve)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "pallas"])
+def test_ntt_large_two_and_three_pass(h2, curve):
+    for log_n in (18, 20, 21):
+        n = 1 << log_n
+        a = rand_scalars(curve, n, seed=log_n)
+        w = omega_limbs(curve, log_n)
+        want = O.best_fft(O.CURVE_SCALAR_FIELD[CID[curve]], a, w, log_n, threads=8).reshape(n, 4)
+        got = a.copy()
+        h2.best_fft(got, w, log_n, curve)
+        assert np.array_equal(got, want), log_n
+
+
+def test_ntt_inverse_round_trip_and_batch(h2):
+    curve, log_n = "bn254", 12
+    n = 1 << log_n
+    f = scalar_field(curve)
+    cols = [rand_scalars(curve, n, seed=10 + j) for j in range(3)]
+    orig = [c.copy() for c in cols]
+    h2.best_fft_batch(cols, omega_limbs(curve, log_n), log_n, curve)
+    for c, o in zip(cols, orig):
+        want = O.best_fft(1, o, omega_limbs(curve, log_n), log_n).reshape(n, 4)
+        assert np.array_equal(c, want)
+    h2.best_fft_batch(cols, omega_limbs(curve, log_n, inverse=True), log_n, curve)
+    # iNTT(NTT(a)) = n * a  (best_fft does not scale; EvaluationDomain::ifft multiplies by n^-1)
+    n_m = np.array(f.limbs(n), dtype=np.uint64)
+    for c, o in zip(cols, orig):
+        want = O.field_mul_many(1, o.reshape(-1), np.tile(n_m, n)).reshape(n, 4)
+        assert np.array_equal(c, want)
+
+
+def test_ntt_rejects_bad_length(h2):
+    a = rand_scalars("bn254", 8)
+    with pytest.raises(ValueError):
+        h2.best_fft(a, omega_limbs("bn254", 4), 4, "bn254")
+
+
+# ------------------------------------------------------------------------------- MSM ----
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 31, 33, 1000, 2048, 1 << 14])
+def test_msm_matches_oracle(h2, curve, n):
+    s = rand_scalars(curve, n, seed=n & 0xFF)
+    b = rand_bases(curve, n)
+    want = norm(curve, O.best_multiexp(CID[curve], s, b, threads=8))
+    got = norm(curve, h2.best_multiexp(s, b, curve))
+    assert np.array_equal(got, want)
+    assert O.is_on_curve(CID[curve], got)
+
+
+def test_msm_2_16_bn254_and_pallas(h2):
+    for curve in ("bn254", "pallas"):
+        n = 1 << 16
+        s = rand_scalars(curve, n, seed=7)
+        b = rand_bases(curve, n)
+        want = norm(curve, O.best_multiexp(CID[curve], s, b, threads=8))
+        got = norm(curve, h2.best_multiexp(s, b, curve))
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "pallas"])
+def test_msm_edge_scalars(h2, curve):
+    """zeros are skipped, ones / p-1 / small values hit the sign and carry paths."""
+    n = 300
+    f = scalar_field(curve)
+    b = rand_bases(curve, n)
+    vals = [0, 1, 2, f.p - 1, f.p - 2, (1 << 128) - 1, 1 << 253, (f.p - 1) // 2, (f.p + 1) // 2, 0x8000, 0x7FFF,
+            0xFFFF, 0x10000]
+    s = np.array([f.limbs(vals[i % len(vals)]) for i in range(n)], dtype=np.uint64)
+    want = norm(curve, O.best_multiexp(CID[curve], s, b))
+    got = norm(curve, h2.best_multiexp(s, b, curve))
+    assert np.array_equal(got, want)
+    # all-zero column -> identity (0,0), as fixed_commitments print `Infinity`
+    z = np.zeros((n, 4), dtype=np.uint64)
+    assert not norm(curve, h2.best_multiexp(z, b, curve)).any()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "pallas"])
+def test_msm_group_law_collisions(h2, curve):
+    """duplicate bases (P + P in one bucket), P and -P with equal scalars (P - P), identity bases."""
+    n = 64
+    c = R.CURVES[curve]
+    b = rand_bases(curve, n)
+    b[1] = b[0]                       # same point twice
+    b[3] = b[2]
+    neg = b[4].copy()
+    y = c.base.from_mont(O.limbs_to_int(neg[4:]))
+    neg[4:] = np.array(c.base.limbs((-y) % c.base.p), dtype=np.uint64)
+    b[5] = neg                        # -P next to P
+    b[6] = 0                          # identity base
+    s = rand_scalars(curve, n, seed=3)
+    s[1] = s[0]
+    s[3] = s[2]
+    s[5] = s[4]
+    want = norm(curve, O.best_multiexp(CID[curve], s, b))
+    got = norm(curve, h2.best_multiexp(s, b, curve))
+    assert np.array_equal(got, want)
+    # everything cancels: s*P + s*(-P) = identity
+    b2 = np.stack([b[4], neg])
+    s2 = np.stack([s[4], s[4]])
+    assert not norm(curve, h2.best_multiexp(s2, b2, curve)).any()
+
+
+def test_msm_hot_bucket_all_ones(h2):
+    """degenerate witness column: every scalar equal -> one bucket per window holds all n points."""
+    curve, n = "bn254", 1 << 13
+    f = scalar_field(curve)
+    b = rand_bases(curve, n)
+    for v in (1, 0x1234567):
+        s = np.tile(np.array(f.limbs(v), dtype=np.uint64), (n, 1))
+        want = norm(curve, O.best_multiexp(CID[curve], s, b, threads=8))
+        got = norm(curve, h2.best_multiexp(s, b, curve))
+        assert np.array_equal(got, want)
+
+
+def test_msm_sparse_witness_shape(h2):
+    """zero except 64 dense rows at the top and 6 at the bottom (SURVEY.md section 8(d) 'sparse')."""
+    curve, n = "bn254", 1 << 12
+    b = rand_bases(curve, n)
+    s = np.zeros((n, 4), dtype=np.uint64)
+    d = rand_scalars(curve, 70, seed=9)
+    s[:64] = d[:64]
+    s[-6:] = d[64:]
+    want = norm(curve, O.best_multiexp(CID[curve], s, b))
+    got = norm(curve, h2.best_multiexp(s, b, curve))
+    assert np.array_equal(got, want)
+
+
+def test_msm_resident_bases_prefix_and_batch(h2):
+    curve, n = "bn254", 4096
+    b = rand_bases(curve, n)
+    bases = h2.Bases(curve, b)
+    try:
+        assert bases.plan()["windows"] * bases.plan()["window_bits"] >= 255
+        cols = [rand_scalars(curve, n, seed=20 + j) for j in range(5)]
+        cols[3][:] = 0
+        got = bases.msm_batch(cols)
+        for j, col in enumerate(cols):
+            want = norm(curve, O.best_multiexp(CID[curve], col, b, threads=8))
+            assert np.array_equal(got[j], want), j
+        # a shorter column uses a prefix of the registered bases
+        short = cols[0][:1000]
+        want = norm(curve, O.best_multiexp(CID[curve], short, b[:1000], threads=4))
+        assert np.array_equal(norm(curve, bases.msm(short)), want)
+        with pytest.raises(ValueError):
+            bases.msm(rand_scalars(curve, n + 1))
+    finally:
+        bases.release()
+
+
+def test_msm_length_mismatch_is_an_error(h2):
+    with pytest.raises(ValueError):
+        h2.best_multiexp(rand_scalars("bn254", 4), rand_bases("bn254", 5), "bn254")
+    import ctypes
+    lib = h2.load()
+    out = np.zeros(12, dtype=np.uint64)
+    s = rand_scalars("bn254", 4)
+    assert lib.h2_msm(0, 0xDEAD, s.ctypes.data, 4, out.ctypes.data) == -4   # H2_EHANDLE
+    assert lib.h2_ntt(7, s.ctypes.data, s.ctypes.data, 2) == -1             # H2_EINVAL
+    assert isinstance(ctypes.c_char_p(lib.h2_strerror(-1)).value, bytes)
