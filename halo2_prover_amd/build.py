@@ -1,14 +1,23 @@
-"""Build libh2hip.so in-tree with hipcc for gfx950 (one translation unit: csrc/h2_capi.hip)."""
+"""Build libh2hip.so in-tree with hipcc for gfx950.
+
+Four translation units: csrc/h2_curve_impl.hip once per curve (-DH2_CURVE_ID=0/1/2; the kernels) and
+csrc/h2_capi.hip (host logic, the C ABI).  They are compiled in parallel and linked into one shared
+library that travels to the GPU box with the repo snapshot.
+"""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "h2_capi.hip")
+CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libh2hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("h2_capi.hip", "h2_msm.hpp", "h2_ntt.hpp", "h2_curve.hpp", "h2_field.hpp", "h2_constants.inc")]
-DEPS.append(os.path.join(os.path.dirname(HERE), "include", "h2hip.h"))
+OBJ = os.path.join(HERE, "build")
+DEPS = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+    os.path.join(os.path.dirname(HERE), "include", "h2hip.h"),
+    os.path.join(os.path.dirname(HERE), "include", "h2hip_selftest.h"),
+]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def needs_build():
@@ -18,14 +27,31 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for cid, name in ((0, "bn254"), (1, "pallas"), (2, "vesta")):
+        obj = os.path.join(OBJ, "curve_%s.o" % name)
+        jobs.append(([hipcc] + FLAGS + list(extra_flags) + ["-DH2_CURVE_ID=%d" % cid, "-c",
+                     os.path.join(CSRC, "h2_curve_impl.hip"), "-o", obj], obj))
+    capi = os.path.join(OBJ, "capi.o")
+    jobs.append(([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, "h2_capi.hip"), "-o", capi], capi))
+
+    def run(job):
+        if verbose:
+            print(" ".join(job[0]), file=sys.stderr)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(run, jobs))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return OUT
 
 

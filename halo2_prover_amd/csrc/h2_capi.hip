@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "h2_curve_ops.hpp"
 #include "h2_msm.hpp"
 #include "h2_ntt.hpp"
 
@@ -90,48 +91,43 @@ int ensure_arena(void** p, size_t* have, size_t want) {
 
 bool curve_ok(int c) { return c == H2_BN254 || c == H2_PALLAS || c == H2_VESTA; }
 
-template <class F>
-int dispatch(int curve, F&& f) {
+const CurveOps* ops_of(int curve) {
   switch (curve) {
-    case H2_BN254: return f(BN254_CURVE{});
-    case H2_PALLAS: return f(PALLAS_CURVE{});
-    case H2_VESTA: return f(VESTA_CURVE{});
+    case H2_BN254: return curve_ops_bn254();
+    case H2_PALLAS: return curve_ops_pallas();
+    case H2_VESTA: return curve_ops_vesta();
   }
-  return H2_EINVAL;
+  return nullptr;
 }
 
 // ---- bases ---------------------------------------------------------------------------------
 int register_device(int curve, const void* d_affine, size_t n, uint64_t* handle_out) {
   if (!g_ctx.ready) return H2_ENOTINIT;
   if (!curve_ok(curve) || !d_affine || !handle_out || n == 0) return H2_EINVAL;
-  return dispatch(curve, [&](auto cv) -> int {
-    using CV = decltype(cv);
-    MsmGeom g = msm_geometry(n, CV::Scalar::NUM_BITS);
-    if ((uint64_t)g.W * n >= (1ull << 31)) return H2_EINVAL;
-    BasesEntry be{};
-    be.curve = curve;
-    be.n = n;
-    be.geom = g;
-    be.table_bytes = (size_t)g.W * n * 64;
-    hipError_t e = hipMalloc(&be.table, be.table_bytes);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      g_ctx.last_error = std::string("hipMalloc(table): ") + hipGetErrorString(e);
-      return H2_ENOMEM;
-    }
-    hipLaunchKernelGGL(msm_table_kernel<CV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_ctx.stream,
-                       (const U128*)d_affine, (U128*)be.table, (uint32_t)n, g);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
-    if (e != hipSuccess) {
-      (void)hipFree(be.table);
-      return dev_fail(e, "msm_table_kernel");
-    }
-    uint64_t h = g_ctx.next_handle++;
-    g_ctx.bases[h] = be;
-    *handle_out = h;
-    return H2_OK;
-  });
+  const CurveOps* ops = ops_of(curve);
+  MsmGeom g = msm_geometry(n, ops->scalar_bits);
+  if ((uint64_t)g.W * n >= (1ull << 31)) return H2_EINVAL;
+  BasesEntry be{};
+  be.curve = curve;
+  be.n = n;
+  be.geom = g;
+  be.table_bytes = (size_t)g.W * n * 64;
+  hipError_t e = hipMalloc(&be.table, be.table_bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    g_ctx.last_error = std::string("hipMalloc(table): ") + hipGetErrorString(e);
+    return H2_ENOMEM;
+  }
+  e = ops->table_build(d_affine, be.table, (uint32_t)n, g, g_ctx.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
+  if (e != hipSuccess) {
+    (void)hipFree(be.table);
+    return dev_fail(e, "msm_table_kernel");
+  }
+  uint64_t h = g_ctx.next_handle++;
+  g_ctx.bases[h] = be;
+  *handle_out = h;
+  return H2_OK;
 }
 
 // ---- MSM -----------------------------------------------------------------------------------
@@ -143,13 +139,10 @@ int msm_enqueue(int curve, const BasesEntry& be, const void* d_scalars, size_t n
   int rc = ensure_arena(&g_ctx.ws, &g_ctx.ws_bytes, ws.total);
   if (rc != H2_OK) return rc;
   *ws_out = ws;
-  return dispatch(curve, [&](auto cv) -> int {
-    using CV = decltype(cv);
-    hipError_t e = msm_launch<CV>((const U128*)be.table, (uint32_t)be.n, (const U128*)d_scalars, n, m, be.geom,
-                                  (char*)g_ctx.ws, ws, stream);
-    if (e != hipSuccess) return dev_fail(e, "msm_launch");
-    return H2_OK;
-  });
+  hipError_t e = ops_of(curve)->msm_launch(be.table, (uint32_t)be.n, d_scalars, n, m, be.geom, (char*)g_ctx.ws, ws,
+                                          stream);
+  if (e != hipSuccess) return dev_fail(e, "msm_launch");
+  return H2_OK;
 }
 
 int msm_common_checks(int curve, uint64_t handle, size_t n, size_t m, const BasesEntry** be) {
@@ -164,21 +157,12 @@ int msm_common_checks(int curve, uint64_t handle, size_t n, size_t m, const Base
 }
 
 // ---- NTT -----------------------------------------------------------------------------------
-int scalar_field_of(int curve) {
-  switch (curve) {
-    case H2_BN254: return BN254_FR::ID;
-    case H2_PALLAS: return PASTA_FQ::ID;
-    case H2_VESTA: return PASTA_FP::ID;
-  }
-  return -1;
-}
-
-template <class FP>
-int get_twiddles(const uint64_t omega[4], uint32_t log_n, hipStream_t stream, const U128** out) {
+int get_twiddles(const CurveOps* ops, const uint64_t omega[4], uint32_t log_n, hipStream_t stream,
+                 const void** out) {
   for (auto& t : g_ctx.twiddles) {
-    if (t.field == FP::ID && t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) {
+    if (t.field == ops->scalar_field_id && t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) {
       t.stamp = ++g_ctx.stamp;
-      *out = (const U128*)t.tw;
+      *out = t.tw;
       return H2_OK;
     }
   }
@@ -186,12 +170,12 @@ int get_twiddles(const uint64_t omega[4], uint32_t log_n, hipStream_t stream, co
     size_t victim = 0;
     for (size_t i = 1; i < g_ctx.twiddles.size(); i++)
       if (g_ctx.twiddles[i].stamp < g_ctx.twiddles[victim].stamp) victim = i;
-    H2_TRY(hipStreamSynchronize(g_ctx.stream));
+    H2_TRY(hipDeviceSynchronize());
     (void)hipFree(g_ctx.twiddles[victim].tw);
     g_ctx.twiddles.erase(g_ctx.twiddles.begin() + victim);
   }
   TwiddleEntry te{};
-  te.field = FP::ID;
+  te.field = ops->scalar_field_id;
   te.log_n = log_n;
   memcpy(te.omega, omega, 32);
   const size_t bytes = (((size_t)1 << log_n) / 2) * 32;
@@ -200,23 +184,22 @@ int get_twiddles(const uint64_t omega[4], uint32_t log_n, hipStream_t stream, co
     (void)hipGetLastError();
     return H2_ENOMEM;
   }
-  Fe<FP> w;
-  memcpy(w.v, omega, 32);
-  e = ntt_build_twiddles<FP>((U128*)te.tw, w, log_n, stream);
+  e = ops->ntt_twiddles(te.tw, omega, log_n, stream);
   if (e != hipSuccess) {
     (void)hipFree(te.tw);
     return dev_fail(e, "ntt_build_twiddles");
   }
   te.stamp = ++g_ctx.stamp;
   g_ctx.twiddles.push_back(te);
-  *out = (const U128*)te.tw;
+  *out = te.tw;
   return H2_OK;
 }
 
-template <class FP>
-int ntt_enqueue_t(void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream) {
-  const U128* tw = nullptr;
-  int rc = get_twiddles<FP>(omega, log_n, stream, &tw);
+int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ops) return H2_EINVAL;
+  const void* tw = nullptr;
+  int rc = get_twiddles(ops, omega, log_n, stream, &tw);
   if (rc != H2_OK) return rc;
   NttPlan pl = ntt_make_plan(log_n);
   void* scratch = nullptr;
@@ -225,18 +208,9 @@ int ntt_enqueue_t(void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, 
     if (rc != H2_OK) return rc;
     scratch = g_ctx.ws;
   }
-  hipError_t e = ntt_launch<FP>((U128*)d_a, (U128*)scratch, tw, log_n, m, stream);
+  hipError_t e = ops->ntt_launch(d_a, scratch, tw, log_n, m, stream);
   if (e != hipSuccess) return dev_fail(e, "ntt_launch");
   return H2_OK;
-}
-
-int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream) {
-  switch (curve) {
-    case H2_BN254: return ntt_enqueue_t<BN254_FR>(d_a, m, omega, log_n, stream);
-    case H2_PALLAS: return ntt_enqueue_t<PASTA_FQ>(d_a, m, omega, log_n, stream);
-    case H2_VESTA: return ntt_enqueue_t<PASTA_FP>(d_a, m, omega, log_n, stream);
-  }
-  return H2_EINVAL;
 }
 
 }  // namespace
@@ -363,14 +337,9 @@ int h2_msm_device(h2_curve_t curve, uint64_t handle, const void* d_scalars, size
   MsmWorkspace ws;
   rc = msm_enqueue((int)curve, *be, d_scalars, n, m, stream, &ws);
   if (rc != H2_OK) return rc;
-  return dispatch((int)curve, [&](auto cv) -> int {
-    using CV = decltype(cv);
-    hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, stream,
-                       (const U128*)((char*)g_ctx.ws + ws.off_tree2), (U128*)d_out_jac, (uint32_t)m);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return dev_fail(e, "msm_to_jacobian_kernel");
-    return H2_OK;
-  });
+  hipError_t e = ops_of((int)curve)->to_jacobian((char*)g_ctx.ws + ws.off_tree2, d_out_jac, (uint32_t)m, stream);
+  if (e != hipSuccess) return dev_fail(e, "msm_to_jacobian_kernel");
+  return H2_OK;
 }
 
 static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* cols, size_t n, size_t m, uint64_t* out,
@@ -397,20 +366,13 @@ static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* co
   rc = msm_enqueue((int)curve, *be, g_ctx.stage, n, m, g_ctx.stream, &ws);
   if (rc != H2_OK) return rc;
   void* d_res = (char*)g_ctx.stage + res_off;
-  rc = dispatch((int)curve, [&](auto cv) -> int {
-    using CV = decltype(cv);
-    const U128* src = (const U128*)((char*)g_ctx.ws + ws.off_tree2);
-    if (affine_out)
-      hipLaunchKernelGGL(msm_to_affine_kernel<CV>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, g_ctx.stream, src,
-                         (U128*)d_res, (uint32_t)m);
-    else
-      hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, g_ctx.stream, src,
-                         (U128*)d_res, (uint32_t)m);
-    hipError_t e = hipGetLastError();
+  {
+    const void* src = (char*)g_ctx.ws + ws.off_tree2;
+    const CurveOps* ops = ops_of((int)curve);
+    hipError_t e = affine_out ? ops->to_affine(src, d_res, (uint32_t)m, g_ctx.stream)
+                              : ops->to_jacobian(src, d_res, (uint32_t)m, g_ctx.stream);
     if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
-    return H2_OK;
-  });
-  if (rc != H2_OK) return rc;
+  }
   H2_TRY(hipMemcpyAsync(out, d_res, m * out_sz, hipMemcpyDeviceToHost, g_ctx.stream));
   H2_TRY(hipStreamSynchronize(g_ctx.stream));
   return H2_OK;
@@ -469,64 +431,25 @@ int h2_ntt(h2_curve_t curve, uint64_t* a, const uint64_t omega[4], uint32_t log_
 
 // ---- host self-test hooks (include/h2hip_selftest.h) ------------------------------------------
 #include "../../include/h2hip_selftest.h"
-namespace {
-template <class FP>
-int selftest_field(int op, const uint64_t* a_, const uint64_t* b_, uint64_t* out) {
-  Fe<FP> a, b, r;
-  memcpy(a.v, a_, 32);
-  memcpy(b.v, b_, 32);
-  switch (op) {
-    case 0: r = fe_add(a, b); break;
-    case 1: r = fe_sub(a, b); break;
-    case 2: r = fe_mul(a, b); break;
-    case 3: r = fe_inv(a); break;
-    case 4: r = fe_to_mont(a); break;
-    case 5: r = fe_from_mont(a); break;
-    case 6: r = fe_neg(a); break;
-    default: return H2_EINVAL;
-  }
-  memcpy(out, r.v, 32);
-  return H2_OK;
-}
-template <class CV>
-int selftest_curve(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out) {
-  Affine<CV> p, q;
-  memcpy(p.x.v, p_, 32); memcpy(p.y.v, p_ + 4, 32);
-  memcpy(q.x.v, q_, 32); memcpy(q.y.v, q_ + 4, 32);
-  Xyzz<CV> r;
-  switch (op) {
-    case 0: r = xyzz_add_affine(xyzz_from_affine(p), q); break;
-    case 1: r = xyzz_double_affine(p); break;
-    case 2: r = xyzz_add(xyzz_add_affine(xyzz_from_affine(p), q), xyzz_from_affine(q)); break;
-    case 3: {
-      uint32_t k = (uint32_t)q_[0];
-      r = Xyzz<CV>::identity();
-      Xyzz<CV> base = xyzz_from_affine(p);
-      for (int bit = 31; bit >= 0; bit--) {
-        r = xyzz_double(r);
-        if ((k >> bit) & 1) r = xyzz_add(r, base);
-      }
-      break;
-    }
-    default: return H2_EINVAL;
-  }
-  Affine<CV> a = xyzz_to_affine(r);
-  memcpy(out, a.x.v, 32);
-  memcpy(out + 4, a.y.v, 32);
-  return H2_OK;
-}
-}  // namespace
 extern "C" int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
   if (!a || !b || !out) return H2_EINVAL;
+  int rc = -1;
   switch (field) {
-    case 0: return selftest_field<BN254_FQ>(op, a, b, out);
-    case 1: return selftest_field<BN254_FR>(op, a, b, out);
-    case 2: return selftest_field<PASTA_FP>(op, a, b, out);
-    case 3: return selftest_field<PASTA_FQ>(op, a, b, out);
+    case 0: rc = curve_ops_bn254()->selftest_field(0, op, a, b, out); break;   // bn254 Fq
+    case 1: rc = curve_ops_bn254()->selftest_field(1, op, a, b, out); break;   // bn254 Fr
+    case 2: rc = curve_ops_pallas()->selftest_field(0, op, a, b, out); break;  // pasta Fp
+    case 3: rc = curve_ops_pallas()->selftest_field(1, op, a, b, out); break;  // pasta Fq
   }
-  return H2_EINVAL;
+  return rc == 0 ? H2_OK : H2_EINVAL;
 }
 extern "C" int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]) {
-  if (!p || !q || !out) return H2_EINVAL;
-  return dispatch(curve, [&](auto cv) -> int { return selftest_curve<decltype(cv)>(op, p, q, out); });
+  const CurveOps* ops = ops_of(curve);
+  if (!ops || !p || !q || !out) return H2_EINVAL;
+  return ops->selftest_curve(op, p, q, out) == 0 ? H2_OK : H2_EINVAL;
+}
+extern "C" int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_for_geometry, uint32_t* out,
+                                  uint32_t cap) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ops || !scalar || !out) return H2_EINVAL;
+  return ops->selftest_digits(scalar, n_for_geometry, out, cap);
 }

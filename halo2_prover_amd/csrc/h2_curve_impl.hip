@@ -1,0 +1,127 @@
+// h2_curve_impl.hip -- kernels and launchers of ONE curve (selected by -DH2_CURVE_ID).
+#include "h2_curve_ops.hpp"
+#include "h2_msm.hpp"
+#include "h2_ntt.hpp"
+
+#include <cstring>
+
+#ifndef H2_CURVE_ID
+#error "compile with -DH2_CURVE_ID=0 (bn254), 1 (pallas) or 2 (vesta)"
+#endif
+
+namespace h2 {
+namespace {
+
+#if H2_CURVE_ID == 0
+using CV = BN254_CURVE;
+#elif H2_CURVE_ID == 1
+using CV = PALLAS_CURVE;
+#else
+using CV = VESTA_CURVE;
+#endif
+using FS = typename CV::Scalar;
+using FB = typename CV::Base;
+
+hipError_t table_build(const void* d_bases, void* d_table, uint32_t n, const MsmGeom& g, hipStream_t s) {
+  hipLaunchKernelGGL(msm_table_kernel<CV>, dim3((n + 255) / 256), dim3(256), 0, s, (const U128*)d_bases,
+                     (U128*)d_table, n, g);
+  return hipGetLastError();
+}
+hipError_t msm_launch_(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t m,
+                       const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s) {
+  return msm_launch<CV>((const U128*)d_table, n_bases, (const U128*)d_scalars, n, m, g, ws_base, ws, s);
+}
+hipError_t to_jacobian(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
+  hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const U128*)d_xyzz,
+                     (U128*)d_out, m);
+  return hipGetLastError();
+}
+hipError_t to_affine(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
+  hipLaunchKernelGGL(msm_to_affine_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const U128*)d_xyzz,
+                     (U128*)d_out, m);
+  return hipGetLastError();
+}
+hipError_t ntt_twiddles(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s) {
+  Fe<FS> w;
+  memcpy(w.v, omega, 32);
+  return ntt_build_twiddles<FS>((U128*)d_tw, w, log_n, s);
+}
+hipError_t ntt_launch_(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m, hipStream_t s) {
+  return ntt_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s);
+}
+
+template <class FP>
+int selftest_field_t(int op, const uint64_t* a_, const uint64_t* b_, uint64_t* out) {
+  Fe<FP> a, b, r;
+  memcpy(a.v, a_, 32);
+  memcpy(b.v, b_, 32);
+  switch (op) {
+    case 0: r = fe_add(a, b); break;
+    case 1: r = fe_sub(a, b); break;
+    case 2: r = fe_mul(a, b); break;
+    case 3: r = fe_inv(a); break;
+    case 4: r = fe_to_mont(a); break;
+    case 5: r = fe_from_mont(a); break;
+    case 6: r = fe_neg(a); break;
+    default: return -1;
+  }
+  memcpy(out, r.v, 32);
+  return 0;
+}
+int selftest_field(int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  return which == 0 ? selftest_field_t<FB>(op, a, b, out) : selftest_field_t<FS>(op, a, b, out);
+}
+int selftest_curve(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out) {
+  Affine<CV> p, q;
+  memcpy(p.x.v, p_, 32); memcpy(p.y.v, p_ + 4, 32);
+  memcpy(q.x.v, q_, 32); memcpy(q.y.v, q_ + 4, 32);
+  Xyzz<CV> r;
+  switch (op) {
+    case 0: r = xyzz_add_affine(xyzz_from_affine(p), q); break;
+    case 1: r = xyzz_double_affine(p); break;
+    case 2: r = xyzz_add(xyzz_add_affine(xyzz_from_affine(p), q), xyzz_from_affine(q)); break;
+    case 3: {
+      uint32_t k = (uint32_t)q_[0];
+      r = Xyzz<CV>::identity();
+      Xyzz<CV> base = xyzz_from_affine(p);
+      for (int bit = 31; bit >= 0; bit--) {
+        r = xyzz_double(r);
+        if ((k >> bit) & 1) r = xyzz_add(r, base);
+      }
+      break;
+    }
+    default: return -1;
+  }
+  Affine<CV> a = xyzz_to_affine(r);
+  memcpy(out, a.x.v, 32);
+  memcpy(out + 4, a.y.v, 32);
+  return 0;
+}
+// out[0..3] = c, W, B, nbits; out[4 + w] = encoded digit of window w (host run of msm_digit_step)
+int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t* out, uint32_t cap) {
+  MsmGeom g = msm_geometry(n_for_geometry, FS::NUM_BITS);
+  if (cap < 4 + g.W) return -1;
+  Fe<FS> s;
+  memcpy(s.v, scalar_mont, 32);
+  s = fe_from_mont(s);
+  out[0] = g.c; out[1] = g.W; out[2] = g.B; out[3] = g.nbits;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < g.W; w++) out[4 + w] = msm_digit_step(s.v, g, w, carry);
+  return carry ? -2 : 0;  // a carry out of the top window would lose value
+}
+
+const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS,   table_build,    msm_launch_,
+                      to_jacobian, to_affine,   ntt_twiddles,   ntt_launch_,    selftest_field,
+                      selftest_curve, selftest_digits};
+
+}  // namespace
+
+#if H2_CURVE_ID == 0
+const CurveOps* curve_ops_bn254() { return &OPS; }
+#elif H2_CURVE_ID == 1
+const CurveOps* curve_ops_pallas() { return &OPS; }
+#else
+const CurveOps* curve_ops_vesta() { return &OPS; }
+#endif
+
+}  // namespace h2

@@ -1,0 +1,40 @@
+// h2_curve_ops.hpp -- per-curve launch table.  Each curve's kernels are compiled in their own
+// translation unit (h2_curve_impl.hip with -DH2_CURVE_ID=0/1/2) so the three build in parallel;
+// h2_capi.hip holds only host logic and calls through this table.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace h2 {
+
+struct U128;
+struct MsmGeom;
+struct MsmWorkspace;
+
+struct CurveOps {
+  int curve_id;
+  int scalar_field_id;
+  uint32_t scalar_bits;
+  // MSM
+  hipError_t (*table_build)(const void* d_bases, void* d_table, uint32_t n, const MsmGeom& g, hipStream_t s);
+  hipError_t (*msm_launch)(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t m,
+                           const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s);
+  hipError_t (*to_jacobian)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
+  hipError_t (*to_affine)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
+  // NTT over the scalar field
+  hipError_t (*ntt_twiddles)(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s);
+  hipError_t (*ntt_launch)(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m,
+                           hipStream_t s);
+  // host self-test hooks (host instantiation of the same templates)
+  int (*selftest_field)(int which /* 0 = base field, 1 = scalar field */, int op, const uint64_t* a,
+                        const uint64_t* b, uint64_t* out);
+  int (*selftest_curve)(int op, const uint64_t* p, const uint64_t* q, uint64_t* out);
+  int (*selftest_digits)(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t* out, uint32_t cap);
+};
+
+const CurveOps* curve_ops_bn254();
+const CurveOps* curve_ops_pallas();
+const CurveOps* curve_ops_vesta();
+
+}  // namespace h2

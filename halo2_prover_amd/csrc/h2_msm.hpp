@@ -70,6 +70,29 @@ msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint3
 }
 
 // ---- digits + histogram -------------------------------------------------------------------
+// One signed-digit step: window w of the canonical scalar v (8 x u32), carry in/out.
+// Returns 0 (no contribution) or |d| | sign<<31 with 1 <= |d| <= 2^(c-1).
+// Invariant: sum_w d_w * 2^(c*w) = v, and the top window never carries out because
+// W*c >= nbits + 1 (msm_geometry).
+H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w, uint32_t& carry) {
+  const uint32_t mask = (1u << g.c) - 1, halfw = 1u << (g.c - 1);
+  const uint32_t bit = w * g.c, limb = bit >> 5, off = bit & 31;
+  uint32_t raw = 0;
+  if (limb < 8) {
+    uint64_t two = v[limb];
+    if (limb + 1 < 8) two |= (uint64_t)v[limb + 1] << 32;
+    raw = (uint32_t)(two >> off) & mask;
+  }
+  raw += carry;
+  if (raw > halfw) {
+    carry = 1;
+    const uint32_t mag = (1u << g.c) - raw;  // digit = raw - 2^c <= 0 (0 when raw == 2^c)
+    return mag ? (mag | MSM_SIGN) : 0u;
+  }
+  carry = 0;
+  return raw;
+}
+
 // digits[(col*W + w)*n + i] = 0 (skip) or |d| | sign<<31 ;  counts[(col*W + w)*B + |d|-1]++
 template <class CV>
 __global__ void __launch_bounds__(256)
@@ -81,36 +104,16 @@ msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ digit
   if (i >= n) return;
   Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
   uint32_t carry = 0;
-  const uint32_t mask = (1u << g.c) - 1, halfw = 1u << (g.c - 1);
   for (uint32_t w = 0; w < g.W; w++) {
-    const uint32_t bit = w * g.c, limb = bit >> 5, off = bit & 31;
-    uint32_t raw = 0;
-    if (limb < 8) {
-      uint64_t two = s.v[limb];
-      if (limb + 1 < 8) two |= (uint64_t)s.v[limb + 1] << 32;
-      raw = (uint32_t)(two >> off) & mask;
-    }
-    raw += carry;
-    uint32_t enc = 0;
-    if (raw > halfw) {
-      const uint32_t mag = (1u << g.c) - raw;  // digit = raw - 2^c < 0
-      carry = 1;
-      enc = mag | MSM_SIGN;
-      atomicAdd(&counts[((size_t)col * g.W + w) * g.B + (mag - 1)], 1u);
-    } else {
-      carry = 0;
-      if (raw != 0) {
-        enc = raw;
-        atomicAdd(&counts[((size_t)col * g.W + w) * g.B + (raw - 1)], 1u);
-      }
-    }
+    const uint32_t enc = msm_digit_step(s.v, g, w, carry);
+    if (enc) atomicAdd(&counts[((size_t)col * g.W + w) * g.B + ((enc & ~MSM_SIGN) - 1)], 1u);
     digits[((size_t)col * g.W + w) * n + i] = enc;
   }
 }
 
 // ---- exclusive scan over K counts (three small kernels) -------------------------------------
 constexpr uint32_t SCAN_BLOCK = 1024;  // elements per block (256 threads x 4)
-__global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, uint32_t* block_sums, size_t K) {
+static __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, uint32_t* block_sums, size_t K) {
   __shared__ uint32_t sh[256];
   const size_t base = (size_t)blockIdx.x * SCAN_BLOCK;
   uint32_t s = 0;
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, ui
   if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
 }
 // single block: exclusive scan of nb block sums in place; total -> *total_out
-__global__ void __launch_bounds__(1024) scan_blocksums_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out) {
+static __global__ void __launch_bounds__(1024) scan_blocksums_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out) {
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(1024) scan_blocksums_kernel(uint32_t* block_su
   if (threadIdx.x == 0) *total_out = carry;
 }
 // offsets[i] = exclusive prefix; cursor[i] = same (scatter cursors)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor, size_t K) {
   __shared__ uint32_t sh[256];
   const size_t base = (size_t)blockIdx.x * SCAN_BLOCK;
@@ -182,7 +185,7 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
 }
 
 // ---- scatter: sorted[cursor[key]++] = table index | sign -------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
                    uint32_t n, uint32_t n_bases, MsmGeom g) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

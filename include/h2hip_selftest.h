@@ -8,6 +8,7 @@
  */
 #ifndef H2HIP_SELFTEST_H
 #define H2HIP_SELFTEST_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -19,6 +20,11 @@ int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t 
  * 1 = 2 * affine p, 2 = (p + q) + q via xyzz_add of two accumulators, 3 = [k] p (k < 2^32, in q[0])
  * by double-and-add.  p, q: affine (8 limbs); out: affine (8 limbs), identity = zeros. */
 int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]);
+/* host run of the signed-digit window decomposition used by the MSM digits kernel.
+ * scalar: Montgomery limbs; geometry chosen as for `n_for_geometry` registered bases.
+ * out[0..3] = window bits c, windows W, buckets B, scalar bits; out[4 + w] = 0 or |d| | sign << 31.
+ * Returns 0, or a negative value (cap too small / carry out of the top window). */
+int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_for_geometry, uint32_t* out, uint32_t cap);
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,36 @@ def test_host_curve_ops_match_bigint_reference(lib, name):
         assert np.array_equal(_cop(lib, cid, 3, _aff(c, P), kq), _aff(c, c.mul(k, P))), k
     # group order: [q]G = O  (SURVEY.md section 8(a) asks for this assertion on the Pasta curves)
     assert c.mul(c.scalar.p, G) is None
+
+
+@pytest.mark.parametrize("name", list(R.CURVES))
+def test_signed_digit_decomposition_reconstructs_the_scalar(lib, name):
+    """host run of msm_digit_step: sum_w d_w 2^(c w) == scalar, |d| <= 2^(c-1), bucket index in range,
+    no carry out of the top window -- for every window size the geometry can choose."""
+    c = R.CURVES[name]
+    f = c.scalar
+    cid = O.CURVE_IDS[name]
+    rng = random.Random(cid + 17)
+    out = np.zeros(64, dtype=np.uint32)
+    for n_geom in (1, 1 << 10, 1 << 11, 1 << 13, 1 << 16, 1 << 17, 1 << 20, 1 << 22, 1 << 24, 1 << 26):
+        specials = [0, 1, f.p - 1, f.p - 2, (1 << 253) - 1, (1 << f.num_bits) - 1 if (1 << f.num_bits) - 1 < f.p else f.p - 1]
+        for trial in range(60):
+            v = specials[trial] if trial < len(specials) else rng.randrange(f.p)
+            if trial in (10, 11, 12):  # long runs of one bits: raw == 2^c with carry-in
+                v = ((1 << 250) - 1) & ~((1 << rng.randrange(1, 200)) - 1)
+                v |= 1 << rng.randrange(0, 8)
+                v %= f.p
+            s = np.array(f.limbs(v), dtype=np.uint64)
+            rc = lib.h2_selftest_digits(cid, s.ctypes.data, n_geom, out.ctypes.data, 64)
+            assert rc == 0, (n_geom, hex(v), rc)
+            cbits, W, B, nbits = (int(x) for x in out[:4])
+            assert B == 1 << (cbits - 1) and W * cbits >= nbits + 1 and nbits == f.num_bits
+            total = 0
+            for w in range(W):
+                enc = int(out[4 + w])
+                mag = enc & 0x7FFFFFFF
+                assert mag <= B
+                if enc:
+                    assert 1 <= mag
+                total += (-mag if enc >> 31 else mag) << (cbits * w)
+            assert total == v, (n_geom, hex(v))
