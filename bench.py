@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""bench.py -- MSM + NTT throughput of the halo2 hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--curve pallas|bn254|vesta] [--workload ...]
+
+One "step" = one pass of the hot path over the MSM/NTT calls of ONE Poseidon k=16 proof
+(BASELINE.json metric "MSM+NTT field-ops/s ... Poseidon k=16"; call counts from SURVEY.md
+section 8(a)/App. A.4), with dense synthetic columns already resident in HBM:
+
+    MSM  n = 2^16 : 4 advice + 2 permutation (over g_lagrange), 1 random-poly + 5 h pieces + 4 GWC
+                    quotients (over g) = 16 MSMs, issued phase by phase (m = 4, 2, 1, 5, 4) as
+                    Fiat-Shamir orders them
+    NTT           : 7 x iNTT(2^16), 7 x NTT(2^19), 1 x iNTT(2^19)   (extended domain, e = 3)
+
+value = field-ops/s with the reference-parameter yardstick of SURVEY.md section 8(d):
+ops_msm(n) = S*(11n + 32(2^c-1)) + 7*256 with c = ceil(ln n), S = 256/c+1;  ops_ntt(n) = 3*(n/2)*log2 n.
+With N > 1 every rank runs the step on its own columns (weak scaling; columns shard, nothing else
+does) and the per-step commitment vector is all-gathered once over RCCL.
+
+Printed keys beyond the driver contract: "roofline" (bucket-accumulate kernel, HIP-event timed
+inside the library on the launch stream), "cpu_baseline" (the CPU oracle timed on this host,
+rank 0, N = 1 only), "phases_ms".
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODULI = {
+    "bn254_fr": 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
+    "pasta_fp": 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001,
+    "pasta_fq": 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001,
+}
+SCALAR_FIELD = {"bn254": ("bn254_fr", 7, 28), "pallas": ("pasta_fq", 5, 32), "vesta": ("pasta_fp", 5, 32)}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def ops_msm(n):
+    c = 1 if n < 4 else 3 if n < 32 else math.ceil(math.log(n))
+    s = 256 // c + 1
+    return s * (11 * n + 32 * ((1 << c) - 1)) + 7 * 256
+
+
+def ops_ntt(n):
+    return 3 * (n // 2) * int(math.log2(n))
+
+
+def limbs(v):
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def splitmix_columns(seed, n, p):
+    """n field elements: SplitMix64 -> 4 limbs, top limb masked to 62 bits, one conditional subtract of
+    the modulus.  The 256-bit patterns are used directly as the in-memory
+    (Montgomery) representation: any value < p is a valid element."""
+    idx = np.arange(1, 4 * n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    a = z.reshape(n, 4).copy()
+    a[:, 3] &= np.uint64((1 << 62) - 1)
+    pl = [(p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    # a >= p ?  (lexicographic from the top limb)
+    ge = np.zeros(n, dtype=bool)
+    eq = np.ones(n, dtype=bool)
+    for i in (3, 2, 1, 0):
+        ge |= eq & (a[:, i] > np.uint64(pl[i]))
+        eq &= a[:, i] == np.uint64(pl[i])
+    ge |= eq
+    if ge.any():
+        sub = a[ge]
+        borrow = np.zeros(sub.shape[0], dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for i in range(4):
+                pi = np.uint64(pl[i])
+                d = sub[:, i] - pi - borrow
+                borrow = ((sub[:, i] < pi) | ((sub[:, i] == pi) & (borrow == 1))).astype(np.uint64)
+                sub[:, i] = d
+        a[ge] = sub
+    return a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--curve", default="pallas", choices=["pallas", "bn254", "vesta"])
+    ap.add_argument("--k", type=int, default=16, help="rows = 2^k (Poseidon k=16 is the metric's config)")
+    ap.add_argument("--workload", default="poseidon", choices=["poseidon", "msm", "ntt"],
+                    help="poseidon = the proof-shaped MSM+NTT mix (default); msm / ntt = one kernel family only")
+    ap.add_argument("--msm-cols", type=int, default=1, help="columns per launch for --workload msm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import halo2_prover_amd as h2
+    from halo2_prover_amd import lib as h2lib
+    h2.init(local_rank)
+    L = h2.load()
+    cid = h2.CURVES[args.curve]
+    fname, gen, two_adicity = SCALAR_FIELD[args.curve]
+    p = MODULI[fname]
+    R = (1 << 256) % p
+    k = args.k
+    n = 1 << k
+    ext = 3                                   # Poseidon: degree 6 -> extended_k = k + 3
+    # an explicit (non-NULL) stream: the library maps a NULL stream argument to its own stream, and the
+    # all-gather below must be ordered after the MSM launches, so everything runs on this one
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
+    assert stream != 0
+
+    def to_dev(a):
+        return torch.from_numpy(a.view(np.int64)).to(dev)
+
+    def omega(log_n, inverse=False):
+        root = pow(gen, (p - 1) >> two_adicity, p)
+        w = pow(root, 1 << (two_adicity - log_n), p)
+        if inverse:
+            w = pow(w, -1, p)
+        return limbs(w * R % p)
+
+    # ---- resident inputs -----------------------------------------------------------------------
+    seed = 0x48324D5300000000 | (rank << 16)
+    # two SRS vectors (stand-ins for g and g_lagrange): [s^i]G from two different s, made on device
+    srs = []
+    for j, sval in enumerate((0x1234567 + 977 * rank, 0x7654321 + 31 * rank)):
+        buf = torch.empty((n, 8), dtype=torch.int64, device=dev)
+        s_m = limbs(sval * R % p)
+        h2lib.check(L.h2_srs_generate(cid, s_m.ctypes.data, n, buf.data_ptr(), stream), "h2_srs_generate")
+        torch.cuda.synchronize()
+        srs.append(h2.Bases.from_device(args.curve, buf.data_ptr(), n))
+        del buf
+    g_lagrange, g = srs
+    plan = g.plan()
+
+    phases = [(g_lagrange, 4), (g_lagrange, 2), (g, 1), (g, 5), (g, 4)] if args.workload == "poseidon" else \
+        [(g, args.msm_cols)] if args.workload == "msm" else []
+    n_msm = sum(m for _, m in phases)
+    cols_np = splitmix_columns(seed | 1, max(n_msm, 1) * n, p)
+    msm_cols = to_dev(cols_np)                # (n_msm*n, 4)
+    msm_out = torch.zeros((max(n_msm, 1), 12), dtype=torch.int64, device=dev)
+    if args.workload == "poseidon":
+        ntts = [(k, 7, True), (k + ext, 7, False), (k + ext, 1, True)]
+    elif args.workload == "ntt":
+        ntts = [(k, 1, False)]
+    else:
+        ntts = []
+    ntt_bufs = []
+    for j, (lg, m, inv) in enumerate(ntts):
+        ntt_bufs.append((to_dev(splitmix_columns(seed | (2 + j), m << lg, p)), lg, m, omega(lg, inv)))
+    gathered = torch.zeros((world * max(n_msm, 1), 12), dtype=torch.int64, device=dev) if world > 1 else None
+
+    def msm_phase():
+        off = 0
+        for bases, m in phases:
+            bases.msm_device(msm_cols.data_ptr() + off * n * 32, n, m, msm_out.data_ptr() + off * 96, stream)
+            off += m
+
+    def ntt_phase():
+        for buf, lg, m, w in ntt_bufs:
+            h2.ntt_device(buf.data_ptr(), m, w, lg, args.curve, stream)
+
+    def step():
+        msm_phase()
+        ntt_phase()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, msm_out)   # the one collective: the commitment vector
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L.h2_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = h2lib.Profile()
+    h2lib.check(L.h2_profile_read(ctypes.byref(prof)), "h2_profile_read")
+    L.h2_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-phase timing (outside the timed region; torch events see this stream because the library was
+    # handed torch's current stream)
+    phases_ms = {}
+    for name, fn in (("msm", msm_phase), ("ntt", ntt_phase)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        phases_ms[name] = round(e0.elapsed_time(e1) / 3, 4)
+
+    ops_step = n_msm * ops_msm(n) + sum(m * ops_ntt(1 << lg) for _, lg, m, _ in ntt_bufs)
+    value = world * ops_step * args.steps / dt
+
+    roofline = None
+    if prof.launches:
+        achieved = prof.algorithmic_bytes / (prof.kernel_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                    "traffic": None,
+                    "avg_kernel_ms": round(prof.kernel_ms / prof.launches, 5), "launches": int(prof.launches),
+                    "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / prof.launches, 1)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R)
+
+    if rank == 0:
+        workload = {"poseidon": "poseidon_k%d_proof_shape: 16 MSM(2^%d) in phases m=4,2,1,5,4 + 7 iNTT(2^%d) + "
+                                "7 NTT(2^%d) + 1 iNTT(2^%d)" % (k, k, k, k + ext, k + ext),
+                    "msm": "msm(2^%d) x %d columns" % (k, args.msm_cols), "ntt": "ntt(2^%d)" % k}[args.workload]
+        out = {
+            "metric": "MSM+NTT field-ops/s", "value": value, "unit": "field-ops/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (256-bit modular)",
+            "data": "synthetic",
+            "config": {"workload": workload, "curve": args.curve, "k": k, "columns_per_gpu": n_msm,
+                       "parallelism": "columns sharded over %d rank(s), 1 all-gather/step" % world,
+                       "msm_window_bits": plan["window_bits"], "msm_windows": plan["windows"],
+                       "msm_table_bytes": plan["table_bytes"]},
+            "roofline": roofline, "cpu_baseline": cpu, "phases_ms": phases_ms,
+            "field_ops_per_step": ops_step,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R):
+    """Time the CPU oracle (restatement of best_multiexp / best_fft, oracle/h2_oracle.c) on this host.
+    Bounded sample: 2 MSM(2^k) + 1 NTT(2^k) + 1 NTT(2^(k+3)) -- the step's 16 : 7 : 8 mix scaled down."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib as O
+    cid = O.CURVE_IDS[args.curve]
+    fid = O.CURVE_SCALAR_FIELD[cid]
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = max(1, min(cores, 64))
+    if args.workload == "ntt":
+        n_m = 0
+    else:
+        n_m = 2
+    bases = O.synth_bases(cid, 0x48324D53000000B5, n, threads=threads) if n_m else None
+    root = pow(gen, (p - 1) >> two_adicity, p)
+
+    def om(lg):
+        return limbs(pow(root, 1 << (two_adicity - lg), p) * R % p)
+
+    t0 = time.perf_counter()
+    for j in range(n_m):
+        O.best_multiexp(cid, cols_np[j * n:(j + 1) * n], bases, threads=threads)
+    t_msm = time.perf_counter() - t0
+    work = n_m * ops_msm(n)
+    t_ntt = 0.0
+    if args.workload != "msm":
+        a = cols_np[:n].copy()
+        big = splitmix_columns(99, n << ext, p) if args.workload == "poseidon" else None
+        t1 = time.perf_counter()
+        O.best_fft(fid, a, om(k), k, threads=threads)
+        work += ops_ntt(n)
+        if big is not None:
+            O.best_fft(fid, big, om(k + ext), k + ext, threads=threads)
+            work += ops_ntt(n << ext)
+        t_ntt = time.perf_counter() - t1
+    total = t_msm + t_ntt
+    return {"value": work / total, "unit": "field-ops/s", "cores": threads, "kind": "port",
+            "sample": "%d MSM(2^%d) + 1 NTT(2^%d)%s with %d threads: %.2f s" %
+                      (n_m, k, k, " + 1 NTT(2^%d)" % (k + ext) if args.workload == "poseidon" else "", threads, total),
+            "msm_s_per_call": (t_msm / n_m) if n_m else None}
+
+
+if __name__ == "__main__":
+    main()

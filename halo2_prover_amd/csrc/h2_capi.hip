@@ -50,6 +50,11 @@ struct Context {
   uint64_t next_handle = 1;
   std::vector<TwiddleEntry> twiddles;
   uint64_t stamp = 0;
+  // kernel timing for the roofline (h2_profile_*): event pairs around the bucket-accumulate kernel
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_alg_bytes = 0;
   std::string last_error;
 };
 
@@ -139,8 +144,21 @@ int msm_enqueue(int curve, const BasesEntry& be, const void* d_scalars, size_t n
   int rc = ensure_arena(&g_ctx.ws, &g_ctx.ws_bytes, ws.total);
   if (rc != H2_OK) return rc;
   *ws_out = ws;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (g_ctx.profiling) {
+    if (g_ctx.prof_used == g_ctx.prof_events.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) g_ctx.prof_events.push_back({a, b});
+    }
+    if (g_ctx.prof_used < g_ctx.prof_events.size()) {
+      ev0 = g_ctx.prof_events[g_ctx.prof_used].first;
+      ev1 = g_ctx.prof_events[g_ctx.prof_used].second;
+      g_ctx.prof_used++;
+      g_ctx.prof_alg_bytes += (double)m * (double)n * 96.0 + (double)m * 96.0;  // SURVEY.md 8(d) bytes_msm
+    }
+  }
   hipError_t e = ops_of(curve)->msm_launch(be.table, (uint32_t)be.n, d_scalars, n, m, be.geom, (char*)g_ctx.ws, ws,
-                                          stream);
+                                          stream, ev0, ev1);
   if (e != hipSuccess) return dev_fail(e, "msm_launch");
   return H2_OK;
 }
@@ -389,6 +407,43 @@ int h2_msm_batch(h2_curve_t curve, uint64_t handle, const uint64_t* const* scala
                  uint64_t* out_affine) {
   std::lock_guard<std::mutex> lk(g_mu);
   return msm_host(curve, handle, scalars, n, m, out_affine, true);
+}
+
+int h2_srs_generate(h2_curve_t curve, const uint64_t s[4], size_t n, void* d_out_affine, void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  const CurveOps* ops = ops_of((int)curve);
+  if (!ops || !s || !d_out_affine || n == 0 || n >= (1ull << 32)) return H2_EINVAL;
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
+  hipError_t e = ops->srs_powers(d_out_affine, s, (uint32_t)n, stream);
+  if (e != hipSuccess) return dev_fail(e, "srs_powers_kernel");
+  return H2_OK;
+}
+
+int h2_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_ctx.profiling = on != 0;
+  g_ctx.prof_used = 0;
+  g_ctx.prof_alg_bytes = 0;
+  return H2_OK;
+}
+
+int h2_profile_read(h2_profile_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!out) return H2_EINVAL;
+  double ms = 0;
+  for (size_t i = 0; i < g_ctx.prof_used; i++) {
+    float t = 0;
+    H2_TRY(hipEventSynchronize(g_ctx.prof_events[i].second));
+    H2_TRY(hipEventElapsedTime(&t, g_ctx.prof_events[i].first, g_ctx.prof_events[i].second));
+    ms += t;
+  }
+  out->launches = g_ctx.prof_used;
+  out->kernel_ms = ms;
+  out->algorithmic_bytes = g_ctx.prof_alg_bytes;
+  g_ctx.prof_used = 0;
+  g_ctx.prof_alg_bytes = 0;
+  return H2_OK;
 }
 
 int h2_ntt_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, void* stream_) {

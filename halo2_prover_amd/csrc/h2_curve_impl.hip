@@ -28,8 +28,16 @@ hipError_t table_build(const void* d_bases, void* d_table, uint32_t n, const Msm
   return hipGetLastError();
 }
 hipError_t msm_launch_(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t m,
-                       const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s) {
-  return msm_launch<CV>((const U128*)d_table, n_bases, (const U128*)d_scalars, n, m, g, ws_base, ws, s);
+                       const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s, hipEvent_t ev_start,
+                       hipEvent_t ev_stop) {
+  return msm_launch<CV>((const U128*)d_table, n_bases, (const U128*)d_scalars, n, m, g, ws_base, ws, s, ev_start,
+                        ev_stop);
+}
+hipError_t srs_powers(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s) {
+  Fe<FS> sv;
+  memcpy(sv.v, s_mont, 32);
+  hipLaunchKernelGGL(srs_powers_kernel<CV>, dim3((n + 255) / 256), dim3(256), 0, s, (U128*)d_out_affine, sv, n);
+  return hipGetLastError();
 }
 hipError_t to_jacobian(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
   hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const U128*)d_xyzz,
@@ -110,9 +118,9 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
   return carry ? -2 : 0;  // a carry out of the top window would lose value
 }
 
-const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS,   table_build,    msm_launch_,
-                      to_jacobian, to_affine,   ntt_twiddles,   ntt_launch_,    selftest_field,
-                      selftest_curve, selftest_digits};
+const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers,
+                      to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, selftest_field, selftest_curve,
+                      selftest_digits};
 
 }  // namespace
 

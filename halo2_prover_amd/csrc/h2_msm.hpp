@@ -332,6 +332,34 @@ __global__ void msm_to_affine_kernel(const U128* __restrict__ in, U128* __restri
   fe_store<B>(out_aff + 4 * (size_t)col + 2, a.y);
 }
 
+// ---- SRS generation: g[i] = [s^i] G  (ParamsKZG::new's coefficient-basis vector) -----------------
+// Device counterpart of the setup loop reached from /root/reference/circuits/src/utils.rs:59-61
+// (SURVEY.md section 3.2).  One thread per point: s^i by square-and-multiply, then a 255-step
+// double-and-add on the generator and one inversion to affine.
+template <class CV>
+__global__ void __launch_bounds__(256)
+srs_powers_kernel(U128* __restrict__ out, Fe<typename CV::Scalar> s, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  using FS = typename CV::Scalar;
+  using FB = typename CV::Base;
+  Fe<FS> k = fe_from_mont(fe_pow_u64(s, (uint64_t)i));
+  Affine<CV> g;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    g.x.v[j] = CV::GX(j);
+    g.y.v[j] = CV::GY(j);
+  }
+  Xyzz<CV> r = Xyzz<CV>::identity();
+  for (int bit = 255; bit >= 0; bit--) {
+    r = xyzz_double(r);
+    if ((k.v[bit >> 5] >> (bit & 31)) & 1) r = xyzz_add_affine(r, g);
+  }
+  Affine<CV> a = xyzz_to_affine(r);
+  fe_store<FB>(out + 4 * (size_t)i, a.x);
+  fe_store<FB>(out + 4 * (size_t)i + 2, a.y);
+}
+
 // ---- workspace layout -------------------------------------------------------------------------
 struct MsmWorkspace {
   size_t K;             // keys = m * W * B
@@ -369,7 +397,8 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
 // Result: m XYZZ points at ws_base + off_tree2.
 template <class CV>
 inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_scalars, size_t n, size_t m,
-                             const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream) {
+                             const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
+                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   uint32_t* digits = (uint32_t*)(ws_base + ws.off_digits);
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
@@ -394,8 +423,10 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
                      cursor, ws.K);
   hipLaunchKernelGGL(msm_scatter_kernel, dim3(nb_n, (unsigned)(m * g.W)), dim3(256), 0, stream, digits, cursor,
                      sorted, (uint32_t)n, n_bases, g);
+  if (ev_start) (void)hipEventRecord(ev_start, stream);
   hipLaunchKernelGGL(msm_accumulate_kernel<CV>, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, table,
                      sorted, offsets, counts, acc, ws.K, hot, misc);
+  if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   hipLaunchKernelGGL(msm_hot_kernel<CV>, dim3(256), dim3(256), 0, stream, table, sorted, offsets, counts, acc, hot,
                      misc);
   hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((g.B + 255) / 256, (unsigned)m), dim3(256), 0, stream, acc, weighted,

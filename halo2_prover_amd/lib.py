@@ -19,6 +19,10 @@ STATUS_NAMES = {0: "H2_OK", -1: "H2_EINVAL", -2: "H2_ENOMEM", -3: "H2_EDEVICE", 
 _P, _Z, _I, _U32, _U64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
 
 
+class Profile(ctypes.Structure):
+    _fields_ = [("launches", _U64), ("kernel_ms", ctypes.c_double), ("algorithmic_bytes", ctypes.c_double)]
+
+
 class MsmPlan(ctypes.Structure):
     _fields_ = [("window_bits", _U32), ("windows", _U32), ("buckets", _U32), ("table_bytes", _U64)]
 
@@ -40,6 +44,9 @@ SYMBOLS = {
     "h2_ntt_batch": (_I, [_I, _P, _Z, _P, _U32]),
     "h2_ntt_device": (_I, [_I, _P, _Z, _P, _U32, _P]),
     "h2_msm_plan": (_I, [_U64, ctypes.POINTER(MsmPlan)]),
+    "h2_srs_generate": (_I, [_I, _P, _Z, _P, _P]),
+    "h2_profile_enable": (_I, [_I]),
+    "h2_profile_read": (_I, [ctypes.POINTER(Profile)]),
 }
 # include/h2hip_selftest.h (host instantiation of the device templates; not a compute path)
 SELFTEST_SYMBOLS = {

@@ -104,6 +104,24 @@ typedef struct {
 } h2_msm_plan_t;
 int h2_msm_plan(uint64_t bases_handle, h2_msm_plan_t* out);
 
+
+/* ---- SRS generation == the g vector of ParamsKZG::new(k) -----------------------------------
+ * d_out_affine[i] = [s^i] G for i < n (device memory, n*64 bytes), s in Montgomery form.
+ * Counterpart of the setup loop reached from /root/reference/circuits/src/utils.rs:59-61 and
+ * wasm.rs:49-55; also how bench.py makes valid synthetic bases without the CPU oracle. */
+int h2_srs_generate(h2_curve_t curve, const uint64_t s[4], size_t n, void* d_out_affine, void* stream);
+
+/* ---- kernel timing for bench.py's roofline ---------------------------------------------------
+ * While enabled, every MSM launch records HIP events (on the launch stream) around its
+ * bucket-accumulate kernel.  h2_profile_read waits for them, returns the sums and resets. */
+typedef struct {
+  uint64_t launches;         /* accumulate-kernel launches timed */
+  double kernel_ms;          /* sum of their durations */
+  double algorithmic_bytes;  /* sum over launches of m*n*(32+64) + m*96 */
+} h2_profile_t;
+int h2_profile_enable(int on);
+int h2_profile_read(h2_profile_t* out);
+
 #ifdef __cplusplus
 }
 #endif
