@@ -105,10 +105,15 @@ int selftest_curve(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out
   memcpy(out + 4, a.y.v, 32);
   return 0;
 }
-// out[0..3] = c, W, B, nbits; out[4 + w] = encoded digit of window w (host run of msm_digit_step)
+// out[0..3] = c, W, B, nbits; out[4 + w] = encoded digit of window w (host run of msm_digit_step);
+// out[4 + W + w] = first bit of window w; out[4 + 2W + w] = its width
 int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t* out, uint32_t cap) {
   MsmGeom g = msm_geometry(n_for_geometry, FS::NUM_BITS);
-  if (cap < 4 + g.W) return -1;
+  if (cap < 4 + 3 * g.W) return -1;
+  for (uint32_t w = 0; w < g.W; w++) {
+    out[4 + g.W + w] = g.off[w];
+    out[4 + 2 * g.W + w] = g.width[w];
+  }
   Fe<FS> s;
   memcpy(s.v, scalar_mont, 32);
   s = fe_from_mont(s);

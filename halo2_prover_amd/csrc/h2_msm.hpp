@@ -8,31 +8,38 @@
 //
 // MI355X-first structure (not the reference's chunk-per-thread serial Pippenger):
 //  * The bases are an SRS that every commitment of a proof reuses, and the GPU has 288 GB of
-//    HBM: at registration the table T[w][i] = 2^(c*w) * P_i (affine) is built once.  Every
-//    c-bit window of a scalar then selects a point of the same weight, so ALL windows share
-//    one set of 2^(c-1) buckets, the per-window running sums shrink to a single one and the
-//    255 serial doublings of the window combination disappear.
-//  * Signed digits (|d| <= 2^(c-1)) halve the bucket count; the sign rides in bit 31 of the
-//    sorted entry and negates y on the fly.
-//  * digits -> histogram -> exclusive scan -> scatter gives, per (window, bucket) key, the
-//    contiguous list of table indices to add; one thread accumulates one key in XYZZ
-//    coordinates with mixed additions (8M + 2S each).  Keys whose list is longer than
-//    MSM_HOT are left to a block-cooperative kernel (degenerate columns: all-ones witnesses).
-//  * bucket weights: P_b = (b+1) * sum_w acc[w][b], then a tree sum.
+//    HBM: at registration the table T[w][i] = 2^(off_w) * P_i (affine) is built once.  Every
+//    window of a scalar then selects a point of the same weight, so ALL windows share ONE set
+//    of 2^(c-1) buckets per column: no per-window running sums, and the 255 serial doublings
+//    of the window combination disappear.
+//  * nbits+1 scalar bits are split into W windows of c or c-1 bits (balanced), so no window is
+//    degenerate; signed digits (|d| <= 2^(width-1)) halve the bucket count, the sign rides in
+//    bit 31 of the sorted entry and negates y on the fly.
+//  * sort by bucket: digits kernel (LDS histogram per block, one global atomic per block and
+//    bucket) -> exclusive scan -> scatter (LDS cursors), giving per bucket the contiguous list
+//    of table indices to add.
+//  * accumulate = segmented reduction with perfect load balance: every thread adds exactly T
+//    consecutive sorted entries (mixed XYZZ additions, 8M + 2S) whatever bucket they belong
+//    to, writes complete runs straight to the bucket and its cut-off head / tail runs to
+//    partial slots; a fix-up kernel sums each bucket's pieces with G lanes and a DPP shuffle
+//    tree, multiplies by the bucket weight (b+1) and a two-level tree sums the buckets.
 #pragma once
 #include "h2_curve.hpp"
 
 namespace h2 {
 
-constexpr uint32_t MSM_HOT = 2048;        // longer key lists go to the cooperative kernel
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr uint32_t MSM_TREE_SEG = 2048;   // points summed by one block of msm_tree_sum_kernel
+constexpr uint32_t MSM_MAX_WINDOWS = 48;
+constexpr uint32_t MSM_MAX_C = 16;        // B*4 bytes of LDS histogram must fit one CU: 2^15 * 4 = 128 KiB
 
 struct MsmGeom {
-  uint32_t c;        // window bits
+  uint32_t c;        // widest window, bits
   uint32_t W;        // windows
-  uint32_t B;        // buckets = 2^(c-1)
+  uint32_t B;        // buckets per column = 2^(c-1)
   uint32_t nbits;    // scalar field bits
+  uint8_t off[MSM_MAX_WINDOWS];    // first bit of window w
+  uint8_t width[MSM_MAX_WINDOWS];  // bits of window w (c or c-1)
 };
 
 inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
@@ -40,16 +47,24 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   int c = (int)lg - 4;
   if (c < 6) c = 6;
-  if (c > 20) c = 20;
-  MsmGeom g;
-  g.c = (uint32_t)c;
+  if (c > (int)MSM_MAX_C) c = (int)MSM_MAX_C;
+  MsmGeom g{};
   g.nbits = nbits;
-  g.W = (nbits + 1 + g.c - 1) / g.c;
+  const uint32_t total = nbits + 1;  // one spare bit: the top window never carries out
+  g.W = (total + c - 1) / c;
+  const uint32_t base = total / g.W, extra = total % g.W;
+  uint32_t o = 0;
+  for (uint32_t w = 0; w < g.W; w++) {
+    g.off[w] = (uint8_t)o;
+    g.width[w] = (uint8_t)(base + (w < extra ? 1 : 0));
+    o += g.width[w];
+  }
+  g.c = base + (extra ? 1 : 0);
   g.B = 1u << (g.c - 1);
   return g;
 }
 
-// ---- table build: T[w][i] = 2^(c*w) * P_i, affine ------------------------------------------
+// ---- table build: T[w][i] = 2^(off_w) * P_i, affine -----------------------------------------
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint32_t n, MsmGeom g) {
@@ -64,50 +79,56 @@ msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint3
     fe_store<B>(dst, a.x);
     fe_store<B>(dst + 2, a.y);
     if (w + 1 < g.W) {
-      for (uint32_t k = 0; k < g.c; k++) cur = xyzz_double(cur);
+      for (uint32_t k = 0; k < g.width[w]; k++) cur = xyzz_double(cur);
     }
   }
 }
 
-// ---- digits + histogram -------------------------------------------------------------------
-// One signed-digit step: window w of the canonical scalar v (8 x u32), carry in/out.
-// Returns 0 (no contribution) or |d| | sign<<31 with 1 <= |d| <= 2^(c-1).
-// Invariant: sum_w d_w * 2^(c*w) = v, and the top window never carries out because
-// W*c >= nbits + 1 (msm_geometry).
+// ---- signed window digits -------------------------------------------------------------------
+// One step: window w of the canonical scalar v (8 x u32), carry in/out.
+// Returns 0 (no contribution) or |d| | sign<<31 with 1 <= |d| <= 2^(width_w - 1) <= B.
+// Invariant: sum_w d_w * 2^(off_w) = v; the top window never carries out (spare bit).
 H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w, uint32_t& carry) {
-  const uint32_t mask = (1u << g.c) - 1, halfw = 1u << (g.c - 1);
-  const uint32_t bit = w * g.c, limb = bit >> 5, off = bit & 31;
-  uint32_t raw = 0;
-  if (limb < 8) {
-    uint64_t two = v[limb];
-    if (limb + 1 < 8) two |= (uint64_t)v[limb + 1] << 32;
-    raw = (uint32_t)(two >> off) & mask;
-  }
-  raw += carry;
+  const uint32_t width = g.width[w], bit = g.off[w];
+  const uint32_t mask = (1u << width) - 1, halfw = 1u << (width - 1);
+  const uint32_t limb = bit >> 5, off = bit & 31;
+  uint64_t two = v[limb];
+  if (limb + 1 < 8) two |= (uint64_t)v[limb + 1] << 32;
+  uint32_t raw = ((uint32_t)(two >> off) & mask) + carry;
   if (raw > halfw) {
     carry = 1;
-    const uint32_t mag = (1u << g.c) - raw;  // digit = raw - 2^c <= 0 (0 when raw == 2^c)
+    const uint32_t mag = (1u << width) - raw;  // digit = raw - 2^width <= 0 (0 when raw == 2^width)
     return mag ? (mag | MSM_SIGN) : 0u;
   }
   carry = 0;
   return raw;
 }
 
-// digits[(col*W + w)*n + i] = 0 (skip) or |d| | sign<<31 ;  counts[(col*W + w)*B + |d|-1]++
+// digits[(col*W + w)*n + i] = 0 | (|d| | sign<<31);  counts[col*B + |d|-1] += 1 through an LDS
+// histogram (one global atomic per block and non-empty bucket).  grid = (tiles, m), dynamic LDS B*4.
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
-                  uint32_t n, size_t col_stride /* elements */, MsmGeom g) {
+                  uint32_t n, size_t col_stride /* elements */, uint32_t tile, MsmGeom g) {
   using S = typename CV::Scalar;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ uint32_t hist[];
   const uint32_t col = blockIdx.y;
-  if (i >= n) return;
-  Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
-  uint32_t carry = 0;
-  for (uint32_t w = 0; w < g.W; w++) {
-    const uint32_t enc = msm_digit_step(s.v, g, w, carry);
-    if (enc) atomicAdd(&counts[((size_t)col * g.W + w) * g.B + ((enc & ~MSM_SIGN) - 1)], 1u);
-    digits[((size_t)col * g.W + w) * n + i] = enc;
+  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * tile, hi = min(lo + tile, n);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < g.W; w++) {
+      const uint32_t enc = msm_digit_step(s.v, g, w, carry);
+      if (enc) atomicAdd(&hist[(enc & ~MSM_SIGN) - 1], 1u);
+      digits[((size_t)col * g.W + w) * n + i] = enc;
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) {
+    const uint32_t h = hist[b];
+    if (h) atomicAdd(&counts[(size_t)col * g.B + b], h);
   }
 }
 
@@ -130,7 +151,8 @@ static __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t*
   if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
 }
 // single block: exclusive scan of nb block sums in place; total -> *total_out
-static __global__ void __launch_bounds__(1024) scan_blocksums_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out) {
+static __global__ void __launch_bounds__(1024)
+scan_blocksums_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out) {
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -154,7 +176,7 @@ static __global__ void __launch_bounds__(1024) scan_blocksums_kernel(uint32_t* b
   }
   if (threadIdx.x == 0) *total_out = carry;
 }
-// offsets[i] = exclusive prefix; cursor[i] = same (scatter cursors)
+// offsets[i] = exclusive prefix (offsets[K] = total); cursor[i] = same (scatter cursors)
 static __global__ void __launch_bounds__(256)
 scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor, size_t K) {
   __shared__ uint32_t sh[256];
@@ -181,25 +203,50 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
       cursor[idx] = run;
     }
     run += v[k];
+    if (idx + 1 == K) offsets[K] = run;
   }
 }
 
-// ---- scatter: sorted[cursor[key]++] = table index | sign -------------------------------------
+// ---- scatter: same tiling as the digits kernel.  LDS histogram of the tile, one global atomic per
+// non-empty bucket reserves the tile's range in the bucket's list, then LDS cursors place the entries.
+// sorted_ref[pos] = (w * n_bases + i) | sign ; sorted_key[pos] = col*B + bucket
 static __global__ void __launch_bounds__(256)
-msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
-                   uint32_t n, uint32_t n_bases, MsmGeom g) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t cw = blockIdx.y;  // col*W + w
-  if (i >= n) return;
-  const uint32_t enc = digits[(size_t)cw * n + i];
-  if (enc == 0) return;
-  const uint32_t w = cw % g.W;
-  const uint32_t mag = enc & ~MSM_SIGN;
-  const uint32_t pos = atomicAdd(&cursor[(size_t)cw * g.B + (mag - 1)], 1u);
-  sorted[pos] = (w * n_bases + i) | (enc & MSM_SIGN);
+msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
+                   uint32_t* __restrict__ sorted_ref, uint32_t* __restrict__ sorted_key, uint32_t n, uint32_t n_bases,
+                   uint32_t tile, MsmGeom g) {
+  extern __shared__ uint32_t hist[];
+  const uint32_t col = blockIdx.y;
+  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * tile, hi = min(lo + tile, n);
+  for (uint32_t w = 0; w < g.W; w++) {
+    const uint32_t* d = digits + ((size_t)col * g.W + w) * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      const uint32_t enc = d[i];
+      if (enc) atomicAdd(&hist[(enc & ~MSM_SIGN) - 1], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) {
+    const uint32_t h = hist[b];
+    if (h) hist[b] = atomicAdd(&cursor[(size_t)col * g.B + b], h);  // now: next free position of this tile
+  }
+  __syncthreads();
+  for (uint32_t w = 0; w < g.W; w++) {
+    const uint32_t* d = digits + ((size_t)col * g.W + w) * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      const uint32_t enc = d[i];
+      if (enc) {
+        const uint32_t b = (enc & ~MSM_SIGN) - 1;
+        const uint32_t pos = atomicAdd(&hist[b], 1u);
+        sorted_ref[pos] = (w * n_bases + i) | (enc & MSM_SIGN);
+        sorted_key[pos] = col * g.B + b;
+      }
+    }
+  }
 }
 
-// ---- accumulate: one thread per (col, w, bucket) key ------------------------------------------
+// ---- accumulate: every thread adds T consecutive sorted entries ---------------------------------
 template <class CV>
 __device__ __forceinline__ Affine<CV> msm_fetch(const U128* __restrict__ table, uint32_t entry) {
   Affine<CV> p = affine_load<CV>(table + 4 * (size_t)(entry & ~MSM_SIGN));
@@ -207,77 +254,100 @@ __device__ __forceinline__ Affine<CV> msm_fetch(const U128* __restrict__ table, 
   return p;
 }
 
+// Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device.
+// A run (maximal stretch of one key inside the chunk) that holds the key's whole list goes to
+// bucket_sum[key]; a cut-off first run goes to head[t], a cut-off last run to tail[t].
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_accumulate_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ sorted,
-                      const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                      U128* __restrict__ acc, size_t K, uint32_t* __restrict__ hot_list, uint32_t* hot_count) {
-  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= K) return;
-  const uint32_t cnt = counts[key];
+msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ sorted_ref,
+                 const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ offsets, size_t K, uint32_t T,
+                 U128* __restrict__ bucket_sum, U128* __restrict__ head, U128* __restrict__ tail) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t E = offsets[K];
+  const uint64_t lo64 = (uint64_t)t * T;
+  if (lo64 >= E) return;
+  const uint32_t lo = (uint32_t)lo64, hi = (uint32_t)min((uint64_t)E, lo64 + T);
+  uint32_t key = sorted_key[lo];
+  bool first = true;
   Xyzz<CV> a = Xyzz<CV>::identity();
-  if (cnt > MSM_HOT) {
-    const uint32_t slot = atomicAdd(hot_count, 1u);
-    hot_list[slot] = (uint32_t)key;
-  } else {
-    const uint32_t* lst = sorted + offsets[key];
-    for (uint32_t k = 0; k < cnt; k++) a = xyzz_add_affine(a, msm_fetch<CV>(table, lst[k]));
+  for (uint32_t e = lo; e < hi; e++) {
+    const uint32_t k = sorted_key[e];
+    if (k != key) {
+      // the run of `key` ended inside the chunk
+      if (first && offsets[key] != lo) xyzz_store<CV>(head + 8 * (size_t)t, a);
+      else xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
+      first = false;
+      a = Xyzz<CV>::identity();
+      key = k;
+    }
+    a = xyzz_add_affine(a, msm_fetch<CV>(table, sorted_ref[e]));
   }
-  xyzz_store<CV>(acc + 8 * key, a);
+  const bool ends_here = offsets[key + 1] == hi;
+  const bool starts_here = !first || offsets[key] == lo;
+  if (starts_here && ends_here) xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
+  else if (first) xyzz_store<CV>(head + 8 * (size_t)t, a);   // one run spanning the whole chunk, or a cut first run
+  else xyzz_store<CV>(tail + 8 * (size_t)t, a);
 }
 
-// hot keys: one 256-thread block per key, strided partial sums then an LDS tree
+// shuffle an XYZZ point down by `delta` lanes
 template <class CV>
-__global__ void __launch_bounds__(256)
-msm_hot_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ sorted,
-               const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, U128* __restrict__ acc,
-               const uint32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count) {
-  __shared__ U128 sh[256 * 8];
-  const uint32_t nhot = *hot_count;
-  for (uint32_t h = blockIdx.x; h < nhot; h += gridDim.x) {
-    const uint32_t key = hot_list[h];
-    const uint32_t cnt = counts[key];
-    const uint32_t* lst = sorted + offsets[key];
-    Xyzz<CV> a = Xyzz<CV>::identity();
-    for (uint32_t k = threadIdx.x; k < cnt; k += 256) a = xyzz_add_affine(a, msm_fetch<CV>(table, lst[k]));
-    xyzz_store<CV>(sh + 8 * threadIdx.x, a);
-    __syncthreads();
-    for (uint32_t st = 128; st > 0; st >>= 1) {
-      if (threadIdx.x < st) {
-        Xyzz<CV> x = xyzz_load<CV>(sh + 8 * threadIdx.x), y = xyzz_load<CV>(sh + 8 * (threadIdx.x + st));
-        xyzz_store<CV>(sh + 8 * threadIdx.x, xyzz_add(x, y));
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      Xyzz<CV> r = xyzz_load<CV>(sh);
-      xyzz_store<CV>(acc + 8 * (size_t)key, r);
-    }
-    __syncthreads();
+__device__ __forceinline__ Xyzz<CV> xyzz_shfl_down(const Xyzz<CV>& p, uint32_t delta) {
+  Xyzz<CV> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    r.x.v[i] = (uint32_t)__shfl_down((int)p.x.v[i], delta, 64);
+    r.y.v[i] = (uint32_t)__shfl_down((int)p.y.v[i], delta, 64);
+    r.zz.v[i] = (uint32_t)__shfl_down((int)p.zz.v[i], delta, 64);
+    r.zzz.v[i] = (uint32_t)__shfl_down((int)p.zzz.v[i], delta, 64);
   }
+  return r;
 }
 
-// ---- bucket weights: P[col][b] = (b+1) * sum_w acc[col][w][b] ---------------------------------
+// Fix-up + weight: G lanes (G = 2^log_g <= 64) per key.  Sums the key's pieces (if its list was cut
+// across chunks), then lane 0 writes weighted[key] = (bucket + 1) * x.
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_weight_kernel(const U128* __restrict__ acc, U128* __restrict__ weighted, MsmGeom g) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t col = blockIdx.y;
-  if (b >= g.B) return;
+msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g, uint32_t bucket_mask,
+                 const U128* __restrict__ bucket_sum, const U128* __restrict__ head, const U128* __restrict__ tail,
+                 U128* __restrict__ weighted) {
+  const uint32_t G = 1u << log_g;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t key = gt >> log_g;
+  const uint32_t lane = (uint32_t)gt & (G - 1);
+  // all lanes of a wave stay in the shuffle tree together; out-of-range keys work on identities
+  const bool live = key < K;
   Xyzz<CV> x = Xyzz<CV>::identity();
-  for (uint32_t w = 0; w < g.W; w++) x = xyzz_add(x, xyzz_load<CV>(acc + 8 * (((size_t)col * g.W + w) * g.B + b)));
-  // (b+1) * x, MSB-first double-and-add
-  Xyzz<CV> r = Xyzz<CV>::identity();
-  if (!x.is_identity()) {
-    const uint32_t k = b + 1;
-    int top = 31 - __clz(k);
-    r = x;
-    for (int bit = top - 1; bit >= 0; bit--) {
-      r = xyzz_double(r);
-      if ((k >> bit) & 1) r = xyzz_add(r, x);
+  if (live) {
+    const uint32_t s = offsets[key], e = offsets[key + 1];
+    if (e > s) {
+      const uint32_t j0 = s / T, j1 = (e - 1) / T;
+      if (j0 == j1) {
+        if (lane == 0) x = xyzz_load<CV>(bucket_sum + 8 * key);
+      } else {
+        for (uint32_t j = j0 + lane; j <= j1; j += G) {
+          const U128* src = (j == j0 && s != j0 * T) ? tail + 8 * (size_t)j : head + 8 * (size_t)j;
+          x = xyzz_add(x, xyzz_load<CV>(src));
+        }
+      }
     }
   }
-  xyzz_store<CV>(weighted + 8 * ((size_t)col * g.B + b), r);
+  for (uint32_t d = G >> 1; d > 0; d >>= 1) {
+    Xyzz<CV> y = xyzz_shfl_down(x, d);
+    x = xyzz_add(x, y);
+  }
+  if (live && lane == 0) {
+    Xyzz<CV> r = Xyzz<CV>::identity();
+    if (!x.is_identity()) {
+      const uint32_t k = ((uint32_t)key & bucket_mask) + 1;
+      const int top = 31 - __clz(k);
+      r = x;
+      for (int bit = top - 1; bit >= 0; bit--) {
+        r = xyzz_double(r);
+        if ((k >> bit) & 1) r = xyzz_add(r, x);
+      }
+    }
+    xyzz_store<CV>(weighted + 8 * key, r);
+  }
 }
 
 // ---- tree sum: out[col][blockIdx.x] = sum of up to MSM_TREE_SEG points of in[col][...] ----------
@@ -285,7 +355,7 @@ template <class CV>
 __global__ void __launch_bounds__(256)
 msm_tree_sum_kernel(const U128* __restrict__ in, U128* __restrict__ out, uint32_t count /* per column */,
                     uint32_t out_per_col) {
-  __shared__ U128 sh[256 * 8];
+  __shared__ U128 sh[4 * 8];
   const uint32_t col = blockIdx.y;
   const uint32_t base = blockIdx.x * MSM_TREE_SEG;
   Xyzz<CV> a = Xyzz<CV>::identity();
@@ -293,17 +363,13 @@ msm_tree_sum_kernel(const U128* __restrict__ in, U128* __restrict__ out, uint32_
     const uint32_t idx = base + k;
     if (idx < count) a = xyzz_add(a, xyzz_load<CV>(in + 8 * ((size_t)col * count + idx)));
   }
-  xyzz_store<CV>(sh + 8 * threadIdx.x, a);
+  for (uint32_t d = 32; d > 0; d >>= 1) a = xyzz_add(a, xyzz_shfl_down(a, d));
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) xyzz_store<CV>(sh + 8 * wave, a);
   __syncthreads();
-  for (uint32_t st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) {
-      Xyzz<CV> x = xyzz_load<CV>(sh + 8 * threadIdx.x), y = xyzz_load<CV>(sh + 8 * (threadIdx.x + st));
-      xyzz_store<CV>(sh + 8 * threadIdx.x, xyzz_add(x, y));
-    }
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
     Xyzz<CV> r = xyzz_load<CV>(sh);
+    for (uint32_t w = 1; w < 4; w++) r = xyzz_add(r, xyzz_load<CV>(sh + 8 * w));
     xyzz_store<CV>(out + 8 * ((size_t)col * out_per_col + blockIdx.x), r);
   }
 }
@@ -362,31 +428,53 @@ srs_powers_kernel(U128* __restrict__ out, Fe<typename CV::Scalar> s, uint32_t n)
 
 // ---- workspace layout -------------------------------------------------------------------------
 struct MsmWorkspace {
-  size_t K;             // keys = m * W * B
+  size_t K;             // keys = m * B
   size_t E;             // max entries = m * W * n
   size_t nblk;          // scan blocks
+  uint32_t T;           // sorted entries per accumulate thread
+  size_t nchunks;       // ceil(E / T)
+  uint32_t log_g;       // lanes per key in the fix-up kernel = 2^log_g
+  uint32_t tile;        // scalars per block in the digits / scatter kernels
   uint32_t lvl1;        // partials per column after the first tree level
-  size_t off_digits, off_counts, off_offsets, off_cursor, off_blocksums, off_sorted, off_hot, off_misc, off_acc,
-      off_weighted, off_tree1, off_tree2, total;
+  size_t off_digits, off_counts, off_offsets, off_cursor, off_blocksums, off_ref, off_key, off_misc, off_bsum,
+      off_head, off_tail, off_weighted, off_tree1, off_tree2, total;
 };
 inline size_t h2_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   MsmWorkspace ws{};
-  ws.K = m * g.W * g.B;
+  ws.K = m * g.B;
   ws.E = m * g.W * n;
   ws.nblk = (ws.K + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  // enough threads to fill 256 CUs x 4 SIMDs x 4 waves, at least 8 and at most 64 additions each
+  uint64_t T = (ws.E + 262143) / 262144;
+  if (T < 8) T = 8;
+  if (T > 64) T = 64;
+  ws.T = (uint32_t)T;
+  ws.nchunks = (ws.E + T - 1) / T;
+  // pieces per key ~ list length / T + 1
+  const double span = (double)g.W * (double)n / (double)g.B / (double)T + 1.0;
+  uint32_t lg = 0;
+  while ((1u << lg) < span && lg < 6) lg++;
+  ws.log_g = lg;
+  // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
+  size_t tile = (n * m + 1023) / 1024;
+  if (tile < 256) tile = 256;
+  if (tile > n) tile = n;
+  ws.tile = (uint32_t)tile;
   ws.lvl1 = (g.B + MSM_TREE_SEG - 1) / MSM_TREE_SEG;
   size_t o = 0;
   ws.off_digits = o; o = h2_align256(o + ws.E * 4);
   ws.off_counts = o; o = h2_align256(o + ws.K * 4);
-  ws.off_offsets = o; o = h2_align256(o + ws.K * 4);
+  ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
   ws.off_cursor = o; o = h2_align256(o + ws.K * 4);
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
-  ws.off_sorted = o; o = h2_align256(o + ws.E * 4);
-  ws.off_hot = o; o = h2_align256(o + (ws.E / MSM_HOT + 16) * 4);
-  ws.off_misc = o; o = h2_align256(o + 64);  // [0] = hot_count, [1] = total entries
-  ws.off_acc = o; o = h2_align256(o + ws.K * 128);
-  ws.off_weighted = o; o = h2_align256(o + m * g.B * 128);
+  ws.off_ref = o; o = h2_align256(o + ws.E * 4);
+  ws.off_key = o; o = h2_align256(o + ws.E * 4);
+  ws.off_misc = o; o = h2_align256(o + 64);
+  ws.off_bsum = o; o = h2_align256(o + ws.K * 128);
+  ws.off_head = o; o = h2_align256(o + ws.nchunks * 128);
+  ws.off_tail = o; o = h2_align256(o + ws.nchunks * 128);
+  ws.off_weighted = o; o = h2_align256(o + ws.K * 128);
   ws.off_tree1 = o; o = h2_align256(o + m * ws.lvl1 * 128);
   ws.off_tree2 = o; o = h2_align256(o + m * 128);
   ws.total = o;
@@ -394,7 +482,8 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
 }
 
 // Enqueue m MSMs of n terms against `table` (built for n_bases points with geometry g).
-// Result: m XYZZ points at ws_base + off_tree2.
+// Result: m XYZZ points at ws_base + off_tree2.  ev_start / ev_stop (optional) bracket the
+// accumulate (chunk) kernel for the roofline measurement.
 template <class CV>
 inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_scalars, size_t n, size_t m,
                              const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
@@ -404,33 +493,41 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
   uint32_t* cursor = (uint32_t*)(ws_base + ws.off_cursor);
   uint32_t* blocksums = (uint32_t*)(ws_base + ws.off_blocksums);
-  uint32_t* sorted = (uint32_t*)(ws_base + ws.off_sorted);
-  uint32_t* hot = (uint32_t*)(ws_base + ws.off_hot);
+  uint32_t* sref = (uint32_t*)(ws_base + ws.off_ref);
+  uint32_t* skey = (uint32_t*)(ws_base + ws.off_key);
   uint32_t* misc = (uint32_t*)(ws_base + ws.off_misc);
-  U128* acc = (U128*)(ws_base + ws.off_acc);
+  U128* bsum = (U128*)(ws_base + ws.off_bsum);
+  U128* head = (U128*)(ws_base + ws.off_head);
+  U128* tail = (U128*)(ws_base + ws.off_tail);
   U128* weighted = (U128*)(ws_base + ws.off_weighted);
   U128* tree1 = (U128*)(ws_base + ws.off_tree1);
   U128* tree2 = (U128*)(ws_base + ws.off_tree2);
   hipError_t e;
   if ((e = hipMemsetAsync(counts, 0, ws.K * 4, stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(misc, 0, 64, stream)) != hipSuccess) return e;
-  const uint32_t nb_n = (uint32_t)((n + 255) / 256);
-  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(nb_n, (unsigned)m), dim3(256), 0, stream, d_scalars, digits, counts,
-                     (uint32_t)n, n, g);
+  if ((e = hipMemsetAsync(bsum, 0, ws.K * 128, stream)) != hipSuccess) return e;   // empty buckets = identity
+  const size_t lds = (size_t)g.B * 4;
+  if (lds > 48 * 1024) {
+    if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds)) != hipSuccess) return e;
+  }
+  const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
+  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(256), lds, stream, d_scalars, digits,
+                     counts, (uint32_t)n, n, ws.tile, g);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      cursor, ws.K);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(nb_n, (unsigned)(m * g.W)), dim3(256), 0, stream, digits, cursor,
-                     sorted, (uint32_t)n, n_bases, g);
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(256), lds, stream, digits, cursor, sref, skey,
+                     (uint32_t)n, n_bases, ws.tile, g);
   if (ev_start) (void)hipEventRecord(ev_start, stream);
-  hipLaunchKernelGGL(msm_accumulate_kernel<CV>, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, table,
-                     sorted, offsets, counts, acc, ws.K, hot, misc);
+  hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
+                     sref, skey, offsets, ws.K, ws.T, bsum, head, tail);
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-  hipLaunchKernelGGL(msm_hot_kernel<CV>, dim3(256), dim3(256), 0, stream, table, sorted, offsets, counts, acc, hot,
-                     misc);
-  hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((g.B + 255) / 256, (unsigned)m), dim3(256), 0, stream, acc, weighted,
-                     g);
+  const size_t fix_threads = ws.K << ws.log_g;
+  hipLaunchKernelGGL(msm_fixup_kernel<CV>, dim3((unsigned)((fix_threads + 255) / 256)), dim3(256), 0, stream, offsets,
+                     ws.K, ws.T, ws.log_g, g.B - 1, bsum, head, tail, weighted);
   hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(ws.lvl1, (unsigned)m), dim3(256), 0, stream, weighted, tree1, g.B,
                      ws.lvl1);
   hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(256), 0, stream, tree1, tree2, ws.lvl1, 1u);

@@ -22,7 +22,8 @@ int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t 
 int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]);
 /* host run of the signed-digit window decomposition used by the MSM digits kernel.
  * scalar: Montgomery limbs; geometry chosen as for `n_for_geometry` registered bases.
- * out[0..3] = window bits c, windows W, buckets B, scalar bits; out[4 + w] = 0 or |d| | sign << 31.
+ * out[0..3] = widest window c, windows W, buckets B, scalar bits; out[4 + w] = 0 or |d| | sign << 31;
+ * out[4 + W + w] = first bit of window w; out[4 + 2W + w] = width of window w (cap >= 4 + 3W).
  * Returns 0, or a negative value (cap too small / carry out of the top window). */
 int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_for_geometry, uint32_t* out, uint32_t cap);
 #ifdef __cplusplus

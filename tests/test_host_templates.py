@@ -114,26 +114,31 @@ def test_signed_digit_decomposition_reconstructs_the_scalar(lib, name):
     f = c.scalar
     cid = O.CURVE_IDS[name]
     rng = random.Random(cid + 17)
-    out = np.zeros(64, dtype=np.uint32)
+    out = np.zeros(160, dtype=np.uint32)
     for n_geom in (1, 1 << 10, 1 << 11, 1 << 13, 1 << 16, 1 << 17, 1 << 20, 1 << 22, 1 << 24, 1 << 26):
-        specials = [0, 1, f.p - 1, f.p - 2, (1 << 253) - 1, (1 << f.num_bits) - 1 if (1 << f.num_bits) - 1 < f.p else f.p - 1]
+        specials = [0, 1, f.p - 1, f.p - 2, (1 << 253) - 1, (1 << 128) - 1, (1 << 200) - (1 << 13)]
         for trial in range(60):
             v = specials[trial] if trial < len(specials) else rng.randrange(f.p)
-            if trial in (10, 11, 12):  # long runs of one bits: raw == 2^c with carry-in
+            if trial in (10, 11, 12):  # long runs of one bits: raw == 2^width with carry-in
                 v = ((1 << 250) - 1) & ~((1 << rng.randrange(1, 200)) - 1)
                 v |= 1 << rng.randrange(0, 8)
                 v %= f.p
             s = np.array(f.limbs(v), dtype=np.uint64)
-            rc = lib.h2_selftest_digits(cid, s.ctypes.data, n_geom, out.ctypes.data, 64)
+            rc = lib.h2_selftest_digits(cid, s.ctypes.data, n_geom, out.ctypes.data, 160)
             assert rc == 0, (n_geom, hex(v), rc)
             cbits, W, B, nbits = (int(x) for x in out[:4])
-            assert B == 1 << (cbits - 1) and W * cbits >= nbits + 1 and nbits == f.num_bits
+            offs = [int(x) for x in out[4 + W:4 + 2 * W]]
+            widths = [int(x) for x in out[4 + 2 * W:4 + 3 * W]]
+            assert B == 1 << (cbits - 1) and nbits == f.num_bits and cbits <= 16
+            # balanced, contiguous windows covering nbits + 1 bits
+            assert offs[0] == 0 and all(offs[w + 1] == offs[w] + widths[w] for w in range(W - 1))
+            assert offs[-1] + widths[-1] == nbits + 1 and max(widths) == cbits and min(widths) >= cbits - 1
             total = 0
             for w in range(W):
                 enc = int(out[4 + w])
                 mag = enc & 0x7FFFFFFF
-                assert mag <= B
+                assert mag <= 1 << (widths[w] - 1) <= B
                 if enc:
                     assert 1 <= mag
-                total += (-mag if enc >> 31 else mag) << (cbits * w)
+                total += (-mag if enc >> 31 else mag) << offs[w]
             assert total == v, (n_geom, hex(v))
