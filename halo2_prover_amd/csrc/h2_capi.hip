@@ -508,3 +508,22 @@ extern "C" int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_
   if (!ops || !scalar || !out) return H2_EINVAL;
   return ops->selftest_digits(scalar, n_for_geometry, out, cap);
 }
+// n element pairs through the DEVICE instantiation (one kernel launch); host pointers in and out
+extern "C" int h2_selftest_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                                           size_t n) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!a || !b || !out || n == 0 || n > (1u << 24) || field < 0 || field > 3) return H2_EINVAL;
+  const CurveOps* ops = field < 2 ? curve_ops_bn254() : curve_ops_pallas();
+  const int which = field & 1;
+  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, 3 * n * 32);
+  if (rc != H2_OK) return rc;
+  char* d = (char*)g_ctx.stage;
+  H2_TRY(hipMemcpyAsync(d, a, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  H2_TRY(hipMemcpyAsync(d + n * 32, b, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  hipError_t e = ops->selftest_field_device(which, op, d, d + n * 32, d + 2 * n * 32, (uint32_t)n, g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "selftest_field_kernel");
+  H2_TRY(hipMemcpyAsync(out, d + 2 * n * 32, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
+  H2_TRY(hipStreamSynchronize(g_ctx.stream));
+  return H2_OK;
+}

@@ -79,6 +79,33 @@ int selftest_field_t(int op, const uint64_t* a_, const uint64_t* b_, uint64_t* o
 int selftest_field(int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   return which == 0 ? selftest_field_t<FB>(op, a, b, out) : selftest_field_t<FS>(op, a, b, out);
 }
+template <class FP>
+__global__ void selftest_field_kernel(int op, const U128* a_, const U128* b_, U128* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<FP> a = fe_load<FP>(a_ + 2 * (size_t)i), b = fe_load<FP>(b_ + 2 * (size_t)i), r;
+  switch (op) {
+    case 0: r = fe_add(a, b); break;
+    case 1: r = fe_sub(a, b); break;
+    case 2: r = fe_mul(a, b); break;
+    case 3: r = fe_inv(a); break;
+    case 4: r = fe_to_mont(a); break;
+    case 5: r = fe_from_mont(a); break;
+    case 7: r = fe_mul_cios(a, b); break;
+    default: r = fe_neg(a); break;
+  }
+  fe_store<FP>(out + 2 * (size_t)i, r);
+}
+hipError_t selftest_field_device(int which, int op, const void* d_a, const void* d_b, void* d_out, uint32_t n,
+                                 hipStream_t s) {
+  if (which == 0)
+    hipLaunchKernelGGL(selftest_field_kernel<FB>, dim3((n + 63) / 64), dim3(64), 0, s, op, (const U128*)d_a,
+                       (const U128*)d_b, (U128*)d_out, n);
+  else
+    hipLaunchKernelGGL(selftest_field_kernel<FS>, dim3((n + 63) / 64), dim3(64), 0, s, op, (const U128*)d_a,
+                       (const U128*)d_b, (U128*)d_out, n);
+  return hipGetLastError();
+}
 int selftest_curve(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out) {
   Affine<CV> p, q;
   memcpy(p.x.v, p_, 32); memcpy(p.y.v, p_ + 4, 32);
@@ -125,7 +152,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers,
                       to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, selftest_field, selftest_curve,
-                      selftest_digits};
+                      selftest_field_device, selftest_digits};
 
 }  // namespace
 

@@ -32,6 +32,9 @@ struct CurveOps {
   int (*selftest_field)(int which /* 0 = base field, 1 = scalar field */, int op, const uint64_t* a,
                         const uint64_t* b, uint64_t* out);
   int (*selftest_curve)(int op, const uint64_t* p, const uint64_t* q, uint64_t* out);
+  // the same field ops run by a device kernel on n element pairs (device pointers)
+  hipError_t (*selftest_field_device)(int which, int op, const void* d_a, const void* d_b, void* d_out, uint32_t n,
+                                      hipStream_t s);
   int (*selftest_digits)(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t* out, uint32_t cap);
 };
 

@@ -134,11 +134,10 @@ H2_HD Fe<FP> fe_dbl(const Fe<FP>& a) {
   return fe_add(a, a);
 }
 
-// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs.  The modulus limbs are
-// compile-time constants, so for the Pasta primes (p = 2^254 + t, p = 1 mod 2^32) the
-// reduction rows collapse to three multiplies and a shift.
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs: the portable form (host side of the
+// library; also the statement the device form below is tested against).
 template <class FP>
-H2_HD Fe<FP> fe_mul(const Fe<FP>& a, const Fe<FP>& b) {
+H2_HD Fe<FP> fe_mul_cios(const Fe<FP>& a, const Fe<FP>& b) {
   uint32_t t[10];
 #pragma unroll
   for (int i = 0; i < 10; i++) t[i] = 0;
@@ -169,6 +168,100 @@ H2_HD Fe<FP> fe_mul(const Fe<FP>& a, const Fe<FP>& b) {
   Fe<FP> r;
   fe_reduce_once<FP>(r.v, t, t[8]);
   return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 form: Montgomery product scanning (Comba / FIPS).  Measured on MI355X (tools/microbench_valu.hip):
+// v_mad_u64_u32 issues every ~5.3 cycles per wave and SIMD, only ~2.3x a 32-bit add, so the cost of a
+// 256-bit product is set by the adds and moves AROUND the 128 multiplies.  Each column keeps a 64-bit
+// accumulator that v_mad_u64_u32 updates in place (no register-pair shuffling) plus a 32-bit count of
+// carry-outs fed by one v_addc_co_u32 per product: 2 instructions per limb product instead of ~4.5 for
+// the CIOS form above (1.3x-1.4x faster end to end).  The modulus limbs are compile-time constants:
+// for the Pasta primes (p = 2^254 + t, p = 1 mod 2^32) the reduction columns collapse to three
+// multiplies, an add and a shift.
+namespace detail {
+// acc += a * b (64-bit, in place); cnt += carry out
+__device__ __forceinline__ void mac_vv(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void mac_vs(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b_const) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(cnt) : "v"(a), "s"(b_const) : "vcc");
+}
+__device__ __forceinline__ void add64(uint64_t& acc, uint32_t& cnt, uint64_t x) {
+  const uint64_t n = acc + x;
+  cnt += (n < x) ? 1u : 0u;
+  acc = n;
+}
+// acc += m * P[J] with the constant limb folded: 0 -> nothing, 1 -> add, 2^s -> shifted add
+template <class FP, int J>
+__device__ __forceinline__ void mac_modulus(uint64_t& acc, uint32_t& cnt, uint32_t m) {
+  constexpr uint32_t pj = FP::P(J);
+  if constexpr (pj == 0) {
+  } else if constexpr (pj == 1) {
+    add64(acc, cnt, (uint64_t)m);
+  } else if constexpr ((pj & (pj - 1)) == 0) {
+    add64(acc, cnt, (uint64_t)m << __builtin_ctz(pj));
+  } else {
+    mac_vs(acc, cnt, m, pj);
+  }
+}
+template <class FP, int K, int I>
+__device__ __forceinline__ void col_ab(uint64_t& acc, uint32_t& cnt, const uint32_t* a, const uint32_t* b) {
+  if constexpr (I <= (K < 8 ? K : 7)) {
+    mac_vv(acc, cnt, a[I], b[K - I]);
+    col_ab<FP, K, I + 1>(acc, cnt, a, b);
+  }
+}
+template <class FP, int K, int I, int IEND>
+__device__ __forceinline__ void col_mp(uint64_t& acc, uint32_t& cnt, const uint32_t* m) {
+  if constexpr (I <= IEND) {
+    mac_modulus<FP, K - I>(acc, cnt, m[I]);
+    col_mp<FP, K, I + 1, IEND>(acc, cnt, m);
+  }
+}
+// column K of  a*b + m*p : low half fixes m[K] so that the column's low word vanishes
+template <class FP, int K>
+__device__ __forceinline__ void columns(uint64_t& acc, uint32_t& cnt, const uint32_t* a, const uint32_t* b,
+                                        uint32_t* m, uint32_t* t) {
+  if constexpr (K < 16) {
+    col_ab<FP, K, (K < 8 ? 0 : K - 7)>(acc, cnt, a, b);
+    if constexpr (K < 8) {
+      col_mp<FP, K, 0, K - 1>(acc, cnt, m);
+      m[K] = (uint32_t)acc * FP::INV;
+      mac_modulus<FP, 0>(acc, cnt, m[K]);
+    } else {
+      if constexpr (K < 15) col_mp<FP, K, K - 7, 7>(acc, cnt, m);
+      t[K - 8] = (uint32_t)acc;
+    }
+    acc = (acc >> 32) | ((uint64_t)cnt << 32);
+    cnt = 0;
+    columns<FP, K + 1>(acc, cnt, a, b, m, t);
+  }
+}
+}  // namespace detail
+
+template <class FP>
+__device__ __forceinline__ Fe<FP> fe_mul_comba(const Fe<FP>& a, const Fe<FP>& b) {
+  uint64_t acc = 0;
+  uint32_t cnt = 0;
+  uint32_t m[8], t[9];
+  detail::columns<FP, 0>(acc, cnt, a.v, b.v, m, t);
+  t[8] = (uint32_t)acc;
+  Fe<FP> r;
+  fe_reduce_once<FP>(r.v, t, t[8]);
+  return r;
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+template <class FP>
+H2_HD Fe<FP> fe_mul(const Fe<FP>& a, const Fe<FP>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return fe_mul_comba(a, b);
+#else
+  return fe_mul_cios(a, b);
+#endif
 }
 template <class FP>
 H2_HD Fe<FP> fe_sqr(const Fe<FP>& a) {

@@ -303,13 +303,13 @@ __device__ __forceinline__ Xyzz<CV> xyzz_shfl_down(const Xyzz<CV>& p, uint32_t d
   return r;
 }
 
-// Fix-up + weight: G lanes (G = 2^log_g <= 64) per key.  Sums the key's pieces (if its list was cut
-// across chunks), then lane 0 writes weighted[key] = (bucket + 1) * x.
+// Fix-up: G lanes (G = 2^log_g <= 64) per key sum the key's pieces when its list was cut across chunks;
+// lane 0 writes xsum[key] (the bucket's point sum).
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g, uint32_t bucket_mask,
+msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g,
                  const U128* __restrict__ bucket_sum, const U128* __restrict__ head, const U128* __restrict__ tail,
-                 U128* __restrict__ weighted) {
+                 U128* __restrict__ xsum) {
   const uint32_t G = 1u << log_g;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> log_g;
@@ -335,19 +335,27 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
     Xyzz<CV> y = xyzz_shfl_down(x, d);
     x = xyzz_add(x, y);
   }
-  if (live && lane == 0) {
-    Xyzz<CV> r = Xyzz<CV>::identity();
-    if (!x.is_identity()) {
-      const uint32_t k = ((uint32_t)key & bucket_mask) + 1;
-      const int top = 31 - __clz(k);
-      r = x;
-      for (int bit = top - 1; bit >= 0; bit--) {
-        r = xyzz_double(r);
-        if ((k >> bit) & 1) r = xyzz_add(r, x);
-      }
+  if (live && lane == 0) xyzz_store<CV>(xsum + 8 * key, x);
+}
+
+// Bucket weights: weighted[key] = (bucket + 1) * xsum[key], one thread per key (MSB-first double-and-add).
+template <class CV>
+__global__ void __launch_bounds__(256)
+msm_weight_kernel(const U128* __restrict__ xsum, U128* __restrict__ weighted, size_t K, uint32_t bucket_mask) {
+  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= K) return;
+  Xyzz<CV> x = xyzz_load<CV>(xsum + 8 * key);
+  Xyzz<CV> r = Xyzz<CV>::identity();
+  if (!x.is_identity()) {
+    const uint32_t k = ((uint32_t)key & bucket_mask) + 1;
+    const int top = 31 - __clz(k);
+    r = x;
+    for (int bit = top - 1; bit >= 0; bit--) {
+      r = xyzz_double(r);
+      if ((k >> bit) & 1) r = xyzz_add(r, x);
     }
-    xyzz_store<CV>(weighted + 8 * key, r);
   }
+  xyzz_store<CV>(weighted + 8 * key, r);
 }
 
 // ---- tree sum: out[col][blockIdx.x] = sum of up to MSM_TREE_SEG points of in[col][...] ----------
@@ -437,7 +445,7 @@ struct MsmWorkspace {
   uint32_t tile;        // scalars per block in the digits / scatter kernels
   uint32_t lvl1;        // partials per column after the first tree level
   size_t off_digits, off_counts, off_offsets, off_cursor, off_blocksums, off_ref, off_key, off_misc, off_bsum,
-      off_head, off_tail, off_weighted, off_tree1, off_tree2, total;
+      off_head, off_tail, off_xsum, off_weighted, off_tree1, off_tree2, total;
 };
 inline size_t h2_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
@@ -453,8 +461,10 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.nchunks = (ws.E + T - 1) / T;
   // pieces per key ~ list length / T + 1
   const double span = (double)g.W * (double)n / (double)g.B / (double)T + 1.0;
+  // 8 lanes per key at most: each lane sums its share of the pieces sequentially, then a 3-level shuffle
+  // tree; wider groups waste most of their lanes in the tree
   uint32_t lg = 0;
-  while ((1u << lg) < span && lg < 6) lg++;
+  while ((1u << lg) < span && lg < 3) lg++;
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
   size_t tile = (n * m + 1023) / 1024;
@@ -474,6 +484,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_bsum = o; o = h2_align256(o + ws.K * 128);
   ws.off_head = o; o = h2_align256(o + ws.nchunks * 128);
   ws.off_tail = o; o = h2_align256(o + ws.nchunks * 128);
+  ws.off_xsum = o; o = h2_align256(o + ws.K * 128);
   ws.off_weighted = o; o = h2_align256(o + ws.K * 128);
   ws.off_tree1 = o; o = h2_align256(o + m * ws.lvl1 * 128);
   ws.off_tree2 = o; o = h2_align256(o + m * 128);
@@ -499,6 +510,7 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   U128* bsum = (U128*)(ws_base + ws.off_bsum);
   U128* head = (U128*)(ws_base + ws.off_head);
   U128* tail = (U128*)(ws_base + ws.off_tail);
+  U128* xsum = (U128*)(ws_base + ws.off_xsum);
   U128* weighted = (U128*)(ws_base + ws.off_weighted);
   U128* tree1 = (U128*)(ws_base + ws.off_tree1);
   U128* tree2 = (U128*)(ws_base + ws.off_tree2);
@@ -527,10 +539,16 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   const size_t fix_threads = ws.K << ws.log_g;
   hipLaunchKernelGGL(msm_fixup_kernel<CV>, dim3((unsigned)((fix_threads + 255) / 256)), dim3(256), 0, stream, offsets,
-                     ws.K, ws.T, ws.log_g, g.B - 1, bsum, head, tail, weighted);
-  hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(ws.lvl1, (unsigned)m), dim3(256), 0, stream, weighted, tree1, g.B,
-                     ws.lvl1);
-  hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(256), 0, stream, tree1, tree2, ws.lvl1, 1u);
+                     ws.K, ws.T, ws.log_g, bsum, head, tail, xsum);
+  hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, xsum, weighted,
+                     ws.K, g.B - 1);
+  if (ws.lvl1 == 1) {
+    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(256), 0, stream, weighted, tree2, g.B, 1u);
+  } else {
+    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(ws.lvl1, (unsigned)m), dim3(256), 0, stream, weighted, tree1, g.B,
+                       ws.lvl1);
+    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(256), 0, stream, tree1, tree2, ws.lvl1, 1u);
+  }
   return hipGetLastError();
 }
 

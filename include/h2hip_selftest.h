@@ -20,6 +20,9 @@ int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t 
  * 1 = 2 * affine p, 2 = (p + q) + q via xyzz_add of two accumulators, 3 = [k] p (k < 2^32, in q[0])
  * by double-and-add.  p, q: affine (8 limbs); out: affine (8 limbs), identity = zeros. */
 int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]);
+/* The same field ops through the DEVICE instantiation (gfx950 Comba multiplier): n element pairs, host
+ * pointers, one kernel launch.  op 7 = the portable CIOS product compiled for the device (cross-check). */
+int h2_selftest_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* host run of the signed-digit window decomposition used by the MSM digits kernel.
  * scalar: Montgomery limbs; geometry chosen as for `n_for_geometry` registered bases.
  * out[0..3] = widest window c, windows W, buckets B, scalar bits; out[4 + w] = 0 or |d| | sign << 31;
