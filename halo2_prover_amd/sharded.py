@@ -1,0 +1,58 @@
+"""Column sharding of one proof phase's commitments across ranks (one process per GPU).
+
+The reference commits the m polynomials of a proof phase one after another against the same bases
+(create_proof, reached from /root/reference/circuits/src/utils.rs:83-91,105-120).
+They are independent, so column j goes to rank j mod world; every rank runs its MSMs on its own GPU
+(bases are replicated at registration, scalars never cross GPUs) and ONE all-gather of the m x 64-byte
+affine commitments over RCCL/xGMI gives every rank the full vector in column order for the transcript.
+There is no other collective on this path.
+"""
+import numpy as np
+
+
+def shard_columns(m, rank, world):
+    """indices of the columns rank `rank` commits to"""
+    return list(range(rank, m, world))
+
+
+def commit_columns(bases, columns, group=None, msm_batch=None):
+    """Commit to `columns` (list of (n, 4) uint64 arrays, identical on every rank) with the columns sharded
+    over the ranks of `group`; returns the (m, 8) affine commitments in column order on every rank.
+
+    `msm_batch` defaults to the GPU path `bases.msm_batch`; tests on CPU (gloo) inject the oracle here --
+    the product itself has no CPU path.
+    """
+    import torch
+    import torch.distributed as dist
+
+    m = len(columns)
+    if msm_batch is None:
+        msm_batch = bases.msm_batch
+    if not (dist.is_available() and dist.is_initialized()):
+        return np.asarray(msm_batch(columns), dtype=np.uint64).reshape(m, 8)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = shard_columns(m, rank, world)
+    local = np.asarray(msm_batch([columns[j] for j in mine]), dtype=np.uint64).reshape(len(mine), 8)
+    slots = (m + world - 1) // world                     # every rank contributes the same number of rows
+    send = np.zeros((slots, 8), dtype=np.uint64)
+    send[:len(mine)] = local
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t_send = torch.from_numpy(send.view(np.int64)).to(dev)
+    t_recv = torch.empty((world * slots, 8), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(t_recv, t_send, group=group)   # the one collective
+    recv = t_recv.cpu().numpy().view(np.uint64).reshape(world, slots, 8)
+    out = np.zeros((m, 8), dtype=np.uint64)
+    for r in range(world):
+        for i, j in enumerate(shard_columns(m, r, world)):
+            out[j] = recv[r, i]
+    return out
+
+
+def split_msm_by_range(n, rank, world):
+    """contiguous point range of a single large MSM handled by `rank`:
+    each rank returns one partial sum, the partials are all-gathered and added (the group is abelian)."""
+    lo = n * rank // world
+    hi = n * (rank + 1) // world
+    return lo, hi
