@@ -468,6 +468,9 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
   size_t tile = (n * m + 1023) / 1024;
+  // a tile should carry a few entries per bucket, or zeroing / flushing the LDS histogram dominates
+  const size_t dense = (size_t)2 * g.B / g.W;
+  if (tile < dense) tile = dense;
   if (tile < 256) tile = 256;
   if (tile > n) tile = n;
   ws.tile = (uint32_t)tile;
