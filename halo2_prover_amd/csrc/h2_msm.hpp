@@ -29,7 +29,7 @@
 namespace h2 {
 
 constexpr uint32_t MSM_SIGN = 0x80000000u;
-constexpr uint32_t MSM_TREE_SEG = 2048;   // points summed by one block of msm_tree_sum_kernel
+constexpr uint32_t MSM_TREE_SEG = 128;    // points summed by one wave of the first tree level
 constexpr uint32_t MSM_MAX_WINDOWS = 48;
 constexpr uint32_t MSM_MAX_C = 16;        // B*4 bytes of LDS histogram must fit one CU: 2^15 * 4 = 128 KiB
 
@@ -358,28 +358,22 @@ msm_weight_kernel(const U128* __restrict__ xsum, U128* __restrict__ weighted, si
   xyzz_store<CV>(weighted + 8 * key, r);
 }
 
-// ---- tree sum: out[col][blockIdx.x] = sum of up to MSM_TREE_SEG points of in[col][...] ----------
+// ---- tree sum: out[col][blockIdx.x] = sum of the `seg` points in[col][blockIdx.x*seg ...] -------------
+// One 64-lane wave per block (so every wave gets a SIMD of its own on a different CU): lanes stride over the
+// segment, then a 6-level DPP shuffle tree.  Level 1 uses seg = 128 (one load + one add + tree = 7 dependent
+// additions), level 2 sums the B/128 partials of a column in one wave.
 template <class CV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 msm_tree_sum_kernel(const U128* __restrict__ in, U128* __restrict__ out, uint32_t count /* per column */,
-                    uint32_t out_per_col) {
-  __shared__ U128 sh[4 * 8];
+                    uint32_t seg, uint32_t out_per_col) {
   const uint32_t col = blockIdx.y;
-  const uint32_t base = blockIdx.x * MSM_TREE_SEG;
+  const uint32_t base = blockIdx.x * seg;
+  const uint32_t end = min(base + seg, count);
   Xyzz<CV> a = Xyzz<CV>::identity();
-  for (uint32_t k = threadIdx.x; k < MSM_TREE_SEG; k += 256) {
-    const uint32_t idx = base + k;
-    if (idx < count) a = xyzz_add(a, xyzz_load<CV>(in + 8 * ((size_t)col * count + idx)));
-  }
+  for (uint32_t idx = base + threadIdx.x; idx < end; idx += 64)
+    a = xyzz_add(a, xyzz_load<CV>(in + 8 * ((size_t)col * count + idx)));
   for (uint32_t d = 32; d > 0; d >>= 1) a = xyzz_add(a, xyzz_shfl_down(a, d));
-  const uint32_t wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) xyzz_store<CV>(sh + 8 * wave, a);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    Xyzz<CV> r = xyzz_load<CV>(sh);
-    for (uint32_t w = 1; w < 4; w++) r = xyzz_add(r, xyzz_load<CV>(sh + 8 * w));
-    xyzz_store<CV>(out + 8 * ((size_t)col * out_per_col + blockIdx.x), r);
-  }
+  if (threadIdx.x == 0) xyzz_store<CV>(out + 8 * ((size_t)col * out_per_col + blockIdx.x), a);
 }
 
 // ---- finish: XYZZ -> Jacobian (m points) ---------------------------------------------------------
@@ -461,10 +455,14 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.nchunks = (ws.E + T - 1) / T;
   // pieces per key ~ list length / T + 1
   const double span = (double)g.W * (double)n / (double)g.B / (double)T + 1.0;
-  // 8 lanes per key at most: each lane sums its share of the pieces sequentially, then a 3-level shuffle
-  // tree; wider groups waste most of their lanes in the tree
+  // lanes per key in the fix-up: as many as the pieces need, but no more than keeps the whole launch
+  // around 128k threads (wider groups waste most of their lanes in the shuffle tree), and at least 8 when
+  // lists are cut at all
   uint32_t lg = 0;
-  while ((1u << lg) < span && lg < 3) lg++;
+  while ((1u << lg) < span && lg < 6) lg++;
+  uint32_t cap = 3;
+  while (cap < 6 && (ws.K << (cap + 1)) <= 131072) cap++;
+  if (lg > cap) lg = cap;
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
   size_t tile = (n * m + 1023) / 1024;
@@ -546,11 +544,13 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, xsum, weighted,
                      ws.K, g.B - 1);
   if (ws.lvl1 == 1) {
-    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(256), 0, stream, weighted, tree2, g.B, 1u);
+    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(64), 0, stream, weighted, tree2, g.B, g.B,
+                       1u);
   } else {
-    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(ws.lvl1, (unsigned)m), dim3(256), 0, stream, weighted, tree1, g.B,
-                       ws.lvl1);
-    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(256), 0, stream, tree1, tree2, ws.lvl1, 1u);
+    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(ws.lvl1, (unsigned)m), dim3(64), 0, stream, weighted, tree1, g.B,
+                       MSM_TREE_SEG, ws.lvl1);
+    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(64), 0, stream, tree1, tree2, ws.lvl1,
+                       ws.lvl1, 1u);
   }
   return hipGetLastError();
 }
