@@ -213,7 +213,8 @@ int get_twiddles(const CurveOps* ops, const uint64_t omega[4], uint32_t log_n, h
   return H2_OK;
 }
 
-int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream) {
+int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream,
+                const uint64_t* scale = nullptr) {
   const CurveOps* ops = ops_of(curve);
   if (!ops) return H2_EINVAL;
   const void* tw = nullptr;
@@ -226,7 +227,7 @@ int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_
     if (rc != H2_OK) return rc;
     scratch = g_ctx.ws;
   }
-  hipError_t e = ops->ntt_launch(d_a, scratch, tw, log_n, m, stream);
+  hipError_t e = ops->ntt_launch(d_a, scratch, tw, log_n, m, stream, scale);
   if (e != hipSuccess) return dev_fail(e, "ntt_launch");
   return H2_OK;
 }
@@ -453,6 +454,62 @@ int h2_ntt_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4]
   hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
   if (log_n == 0) return H2_OK;
   return ntt_enqueue((int)curve, d_a, m, omega, log_n, stream);
+}
+
+int h2_ntt_scaled_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n,
+                         const uint64_t scale[4], void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !omega || !scale || m == 0 || log_n > 30) return H2_EINVAL;
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
+  if (log_n == 0) {
+    hipError_t e = ops_of((int)curve)->poly_scale(d_a, m, scale, stream);
+    if (e != hipSuccess) return dev_fail(e, "poly_scale_kernel");
+    return H2_OK;
+  }
+  return ntt_enqueue((int)curve, d_a, m, omega, log_n, stream, scale);
+}
+
+int h2_poly_scale_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const uint64_t c[4], void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !c) return H2_EINVAL;
+  if (n * m == 0) return H2_OK;
+  hipError_t e = ops_of((int)curve)->poly_scale(d_a, n * m, c, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "poly_scale_kernel");
+  return H2_OK;
+}
+
+int h2_poly_coset_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const uint64_t g[4], void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !g) return H2_EINVAL;
+  if (n * m == 0) return H2_OK;
+  hipError_t e = ops_of((int)curve)->poly_powers(d_a, n, m, g, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "poly_powers_kernel");
+  return H2_OK;
+}
+
+int h2_poly_mul_periodic_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const void* d_t, size_t period,
+                                void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !d_t || period == 0 || (period & (period - 1))) return H2_EINVAL;
+  if (n * m == 0) return H2_OK;
+  hipError_t e = ops_of((int)curve)->poly_mul_periodic(d_a, n * m, d_t, period,
+                                                     stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "poly_mul_periodic_kernel");
+  return H2_OK;
+}
+
+int h2_poly_pointwise_device(h2_curve_t curve, int op, void* d_a, const void* d_b, size_t n, void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !d_b || op < 0 || op > 2) return H2_EINVAL;
+  if (n == 0) return H2_OK;
+  hipError_t e = ops_of((int)curve)->poly_pointwise(d_a, d_b, n, op, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "poly_pointwise_kernel");
+  return H2_OK;
 }
 
 int h2_ntt_batch(h2_curve_t curve, uint64_t* const* cols, size_t m, const uint64_t omega[4], uint32_t log_n) {

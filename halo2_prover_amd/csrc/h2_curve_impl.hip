@@ -2,6 +2,7 @@
 #include "h2_curve_ops.hpp"
 #include "h2_msm.hpp"
 #include "h2_ntt.hpp"
+#include "h2_poly.hpp"
 
 #include <cstring>
 
@@ -54,8 +55,35 @@ hipError_t ntt_twiddles(void* d_tw, const uint64_t omega[4], uint32_t log_n, hip
   memcpy(w.v, omega, 32);
   return ntt_build_twiddles<FS>((U128*)d_tw, w, log_n, s);
 }
-hipError_t ntt_launch_(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m, hipStream_t s) {
-  return ntt_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s);
+hipError_t ntt_launch_(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m, hipStream_t s,
+                       const uint64_t* scale) {
+  Fe<FS> sc;
+  if (scale) memcpy(sc.v, scale, 32);
+  return ntt_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s, scale ? &sc : nullptr);
+}
+hipError_t poly_scale(void* d_a, size_t total, const uint64_t c[4], hipStream_t s) {
+  Fe<FS> cv;
+  memcpy(cv.v, c, 32);
+  hipLaunchKernelGGL(poly_scale_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a, total, cv);
+  return hipGetLastError();
+}
+hipError_t poly_powers(void* d_a, size_t n, size_t m, const uint64_t g[4], hipStream_t s) {
+  Fe<FS> gv;
+  memcpy(gv.v, g, 32);
+  const size_t threads = (n + POLY_RUN - 1) / POLY_RUN;
+  hipLaunchKernelGGL(poly_powers_kernel<FS>, dim3((unsigned)((threads + 255) / 256), (unsigned)m), dim3(256), 0, s,
+                     (U128*)d_a, n, gv);
+  return hipGetLastError();
+}
+hipError_t poly_mul_periodic(void* d_a, size_t total, const void* d_t, size_t period, hipStream_t s) {
+  hipLaunchKernelGGL(poly_mul_periodic_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a, total,
+                     (const U128*)d_t, period - 1);
+  return hipGetLastError();
+}
+hipError_t poly_pointwise(void* d_a, const void* d_b, size_t total, int op, hipStream_t s) {
+  hipLaunchKernelGGL(poly_pointwise_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a,
+                     (const U128*)d_b, total, op);
+  return hipGetLastError();
 }
 
 template <class FP>
@@ -151,7 +179,8 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 }
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers,
-                      to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, selftest_field, selftest_curve,
+                      to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
+                      poly_pointwise, selftest_field, selftest_curve,
                       selftest_field_device, selftest_digits};
 
 }  // namespace

@@ -27,7 +27,12 @@ struct CurveOps {
   // NTT over the scalar field
   hipError_t (*ntt_twiddles)(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s);
   hipError_t (*ntt_launch)(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m,
-                           hipStream_t s);
+                           hipStream_t s, const uint64_t* scale /* 4 limbs or null */);
+  // pointwise polynomial kernels over the scalar field (EvaluationDomain pieces)
+  hipError_t (*poly_scale)(void* d_a, size_t total, const uint64_t c[4], hipStream_t s);
+  hipError_t (*poly_powers)(void* d_a, size_t n, size_t m, const uint64_t g[4], hipStream_t s);
+  hipError_t (*poly_mul_periodic)(void* d_a, size_t total, const void* d_t, size_t period, hipStream_t s);
+  hipError_t (*poly_pointwise)(void* d_a, const void* d_b, size_t total, int op, hipStream_t s);
   // host self-test hooks (host instantiation of the same templates)
   int (*selftest_field)(int which /* 0 = base field, 1 = scalar field */, int op, const uint64_t* a,
                         const uint64_t* b, uint64_t* out);

@@ -27,6 +27,7 @@ struct NttPass {
   uint32_t log_r1;     // radix of pass 0 (0 when this is the only pass)
   uint32_t log_r2;     // radix of pass 1 when there are three passes, else 0
   uint32_t is_final;
+  uint32_t has_scale;  // final pass multiplies every output by `scale` (EvaluationDomain::ifft's n^-1)
 };
 
 __device__ __forceinline__ uint32_t h2_bitrev(uint32_t x, uint32_t bits) {
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(256) ntt_twiddle_kernel(U128* tw, Fe<FP> omega
 template <class FP>
 __global__ void __launch_bounds__(1024)
 ntt_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U128* __restrict__ tw, NttPass P,
-                size_t col_stride /* elements */) {
+                size_t col_stride /* elements */, Fe<FP> scale /* used when P.has_scale (final pass) */) {
   extern __shared__ U128 lds[];
   const uint32_t R = 1u << P.log_r, C = 1u << P.log_c;
   const uint32_t RC = R * C;
@@ -174,6 +175,13 @@ ntt_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U128*
         a0 = U128{x.v[0], x.v[1], x.v[2], x.v[3]};
         a1 = U128{x.v[4], x.v[5], x.v[6], x.v[7]};
       }
+    } else if (P.has_scale) {
+      Fe<FP> x;
+      x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w;
+      x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
+      x = fe_mul(x, scale);
+      a0 = U128{x.v[0], x.v[1], x.v[2], x.v[3]};
+      a1 = U128{x.v[4], x.v[5], x.v[6], x.v[7]};
     }
     U128* g = dst + 2 * (out_base + (uint64_t)k * out_k_stride + (uint64_t)cc * out_c_stride);
     g[0] = a0;
@@ -237,9 +245,10 @@ inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R,
 // data: in place; scratch: m*n elements when the plan has more than one pass.
 template <class FP>
 inline hipError_t ntt_launch(U128* data, U128* scratch, const U128* tw, uint32_t log_n, size_t m,
-                             hipStream_t stream) {
+                             hipStream_t stream, const Fe<FP>* scale = nullptr) {
   if (log_n == 0 || m == 0) return hipSuccess;
   NttPlan pl = ntt_make_plan(log_n);
+  const Fe<FP> sc = scale ? *scale : Fe<FP>::zero();
   const size_t n = (size_t)1 << log_n;
   for (int p = 0; p < pl.npass; p++) {
     const U128* src;
@@ -252,8 +261,10 @@ inline hipError_t ntt_launch(U128* data, U128* scratch, const U128* tw, uint32_t
     hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<FP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ntt_pass_kernel<FP>, grid, dim3(pl.threads[p]), pl.lds_bytes[p], stream, src, dst, tw,
-                       pl.pass[p], n);
+    NttPass P = pl.pass[p];
+    P.has_scale = (scale && P.is_final) ? 1u : 0u;
+    hipLaunchKernelGGL(ntt_pass_kernel<FP>, grid, dim3(pl.threads[p]), pl.lds_bytes[p], stream, src, dst, tw, P, n,
+                       sc);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

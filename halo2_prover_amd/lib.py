@@ -43,6 +43,11 @@ SYMBOLS = {
     "h2_ntt": (_I, [_I, _P, _P, _U32]),
     "h2_ntt_batch": (_I, [_I, _P, _Z, _P, _U32]),
     "h2_ntt_device": (_I, [_I, _P, _Z, _P, _U32, _P]),
+    "h2_ntt_scaled_device": (_I, [_I, _P, _Z, _P, _U32, _P, _P]),
+    "h2_poly_scale_device": (_I, [_I, _P, _Z, _Z, _P, _P]),
+    "h2_poly_coset_device": (_I, [_I, _P, _Z, _Z, _P, _P]),
+    "h2_poly_mul_periodic_device": (_I, [_I, _P, _Z, _Z, _P, _Z, _P]),
+    "h2_poly_pointwise_device": (_I, [_I, _I, _P, _P, _Z, _P]),
     "h2_msm_plan": (_I, [_U64, ctypes.POINTER(MsmPlan)]),
     "h2_srs_generate": (_I, [_I, _P, _Z, _P, _P]),
     "h2_profile_enable": (_I, [_I]),

@@ -94,6 +94,23 @@ int h2_ntt_batch(h2_curve_t curve, uint64_t* const* cols /* m ptrs */, size_t m,
 int h2_ntt_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n,
                   void* stream);
 
+/* ---- EvaluationDomain pieces (halo2_proofs/src/poly/domain.rs) ----
+ * Device-resident columns (m columns, stride n*32 bytes) over the SCALAR field of `curve`; asynchronous on
+ * `stream` (NULL = the library's stream).  With these a column stays in HBM from its Lagrange form through
+ * lagrange_to_coeff / coeff_to_extended / divide_by_vanishing_poly / extended_to_coeff to its commitment. */
+/* best_fft followed by a[i] *= scale, fused into the last pass: EvaluationDomain::ifft(a, omega_inv, k, n^-1) */
+int h2_ntt_scaled_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n,
+                         const uint64_t scale[4], void* stream);
+/* a[i] *= c */
+int h2_poly_scale_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const uint64_t c[4], void* stream);
+/* a[i] *= g^i : distribute_powers_zeta / the coset shift before an extended-domain NTT (and its inverse) */
+int h2_poly_coset_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const uint64_t g[4], void* stream);
+/* a[i] *= t[i mod period], period a power of two: divide_by_vanishing_poly with t = t_evaluations */
+int h2_poly_mul_periodic_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const void* d_t, size_t period,
+                                void* stream);
+/* a[i] = a[i] op b[i] over n elements; op 0 = add, 1 = sub, 2 = mul */
+int h2_poly_pointwise_device(h2_curve_t curve, int op, void* d_a, const void* d_b, size_t n, void* stream);
+
 /* ---- introspection used by bench.py's roofline (no effect on results) --------------------
  * Names the kernels launched by the last h2_msm* / h2_ntt* call and their geometry. */
 typedef struct {

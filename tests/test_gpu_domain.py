@@ -1,0 +1,95 @@
+"""GPU: EvaluationDomain pieces against the big-int restatement, bit for bit,
+and through size-independent properties at k = 16.  The ZETA constant is recalled, not pinned by any reference
+vector ("parity unpinned" for the coset choice; the polynomials it helps compute are unique)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def to_ints(f, t):
+    a = t.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    return [f.from_mont(O.limbs_to_int(r)) for r in a]
+
+
+def from_ints(f, dom, vals):
+    return dom.to_device(np.array([f.limbs(v) for v in vals], dtype=np.uint64))
+
+
+def horner(coeffs, x, p):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % p
+    return acc
+
+
+@pytest.mark.parametrize("curve,j,k", [("bn254", 3, 4), ("bn254", 4, 5), ("bn254", 6, 4), ("pallas", 6, 3), ("vesta", 4, 4)])
+def test_domain_against_bigint(h2, curve, j, k):
+    import torch
+    from halo2_prover_amd.domain import EvaluationDomain
+    f = R.CURVES[curve].scalar
+    dom = EvaluationDomain(j, k, curve)
+    p, n = f.p, 1 << k
+    assert dom.omega == f.omega(k) and dom.extended_omega == f.omega(dom.extended_k)
+    assert (1 << dom.extended_k) >= n * (j - 1) > (1 << (dom.extended_k - 1)) or dom.extended_k == k
+    rng = R.SplitMix64(1000 * j + k)
+    lagr = [R.synth_scalar(rng, p) for _ in range(n)]
+    # lagrange_to_coeff == naive inverse DFT
+    t = from_ints(f, dom, lagr)
+    dom.lagrange_to_coeff(t)
+    coeffs = to_ints(f, t)
+    ninv = pow(n, -1, p)
+    want = [x * ninv % p for x in R.dft_naive(lagr, pow(f.omega(k), -1, p), p)]
+    assert coeffs == want
+    assert [horner(coeffs, pow(f.omega(k), i, p), p) for i in range(n)] == lagr
+    # coeff_to_extended: evaluations on the coset zeta * <extended_omega>
+    ext = dom.coeff_to_extended(t)
+    en = 1 << dom.extended_k
+    got = to_ints(f, ext)
+    assert got == [horner(coeffs, dom.g_coset * pow(dom.extended_omega, i, p) % p, p) for i in range(en)]
+    # divide_by_vanishing_poly: multiply by 1 / (x^n - 1) on the coset
+    ext2 = ext.clone()
+    dom.divide_by_vanishing_poly(ext2)
+    xs = [dom.g_coset * pow(dom.extended_omega, i, p) % p for i in range(en)]
+    assert to_ints(f, ext2) == [g * pow((pow(x, n, p) - 1) % p, -1, p) % p for g, x in zip(got, xs)]
+    # extended_to_coeff undoes coeff_to_extended (padded with zeros up to n*(j-1))
+    back = to_ints(f, dom.extended_to_coeff(ext))
+    assert back == (coeffs + [0] * (n * (j - 1)))[: n * (j - 1)]
+    # pointwise ops and scaling
+    a = from_ints(f, dom, lagr)
+    b = from_ints(f, dom, coeffs)
+    assert to_ints(f, dom.pointwise("mul", a.clone(), b)) == [x * y % p for x, y in zip(lagr, coeffs)]
+    assert to_ints(f, dom.pointwise("add", a.clone(), b)) == [(x + y) % p for x, y in zip(lagr, coeffs)]
+    assert to_ints(f, dom.pointwise("sub", a.clone(), b)) == [(x - y) % p for x, y in zip(lagr, coeffs)]
+    assert to_ints(f, dom.scale(a.clone(), 12345)) == [x * 12345 % p for x in lagr]
+    torch.cuda.synchronize()
+
+
+def test_quotient_of_a_product_k16(h2):
+    """size-independent property at the metric's size (k = 16, degree-3 domain): for random polynomials a, b of
+    degree < n, h = (a*b - r) / (X^n - 1) computed with coset NTTs satisfies a*b = h*(X^n - 1) + r at a random
+    point, where r = a*b mod (X^n - 1) is what the Lagrange-basis product gives."""
+    import torch
+    from halo2_prover_amd.domain import EvaluationDomain
+    curve, j, k = "bn254", 3, 16
+    f = R.CURVES[curve].scalar
+    p, n = f.p, 1 << k
+    dom = EvaluationDomain(j, k, curve)
+    A = O.synth_scalars(1, 0x48324D5300000A01, n).reshape(n, 4)
+    B = O.synth_scalars(1, 0x48324D5300000A02, n).reshape(n, 4)
+    a_l, b_l = dom.to_device(A), dom.to_device(B)           # Lagrange values
+    a_c, b_c = dom.lagrange_to_coeff(a_l.clone()), dom.lagrange_to_coeff(b_l.clone())
+    r_c = dom.lagrange_to_coeff(dom.pointwise("mul", a_l.clone(), b_l))       # (a*b mod X^n-1), coefficients
+    a_e, b_e, r_e = dom.coeff_to_extended(a_c), dom.coeff_to_extended(b_c), dom.coeff_to_extended(r_c)
+    num = dom.pointwise("sub", dom.pointwise("mul", a_e, b_e), r_e)
+    h_c = dom.extended_to_coeff(dom.divide_by_vanishing_poly(num))            # n*(j-1) coefficients
+    torch.cuda.synchronize()
+    x = 0x1234567890ABCDEF1234567890ABCDEF % p
+    ev = lambda t: horner(to_ints(f, t), x, p)  # noqa: E731
+    av, bv, rv, hv = ev(a_c), ev(b_c), ev(r_c), ev(h_c)
+    assert (av * bv - rv - hv * (pow(x, n, p) - 1)) % p == 0
+    # top half of h is zero: deg(a*b) < 2n so deg(h) < n
+    assert not h_c[n:].any().item()
