@@ -269,7 +269,9 @@ int h2_init(int device) {
   }
   if (device < 0 || device >= count) return H2_EINVAL;
   H2_TRY(hipSetDevice(device));
-  H2_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  // a BLOCKING stream on purpose: callers that pass stream = NULL (e.g. PyTorch's legacy default stream)
+  // get work that is ordered against the null stream, so their own copies / kernels see finished results
+  H2_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamDefault));
   g_ctx.device = device;
   g_ctx.ready = true;
   return H2_OK;

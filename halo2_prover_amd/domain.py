@@ -65,6 +65,10 @@ class EvaluationDomain:
         tv = np.stack([_limbs(x * self.R % p) for x in t])
         self.t_evaluations = torch.from_numpy(tv.view(np.int64)).cuda()
         self._L = _lib.load()
+        # limb arrays handed to the C ABI must outlive the call: keep them as attributes
+        self._m = {name: self.mont(getattr(self, name)) for name in
+                   ("omega", "omega_inv", "extended_omega", "extended_omega_inv", "g_coset", "g_coset_inv",
+                    "ifft_divisor", "extended_ifft_divisor")}
 
     # ---- helpers -------------------------------------------------------------------------------
     def mont(self, v):
@@ -90,14 +94,14 @@ class EvaluationDomain:
     def lagrange_to_coeff(self, a):
         """in place: Lagrange basis -> coefficients (ifft with the n^-1 scaling fused into the last NTT pass)"""
         m = self._shape(a, self.n)
-        st = self._L.h2_ntt_scaled_device(self.curve, ctypes.c_void_p(a.data_ptr()), m, self.mont(self.omega_inv).ctypes.data,
-                                          self.k, self.mont(self.ifft_divisor).ctypes.data, self._stream())
+        st = self._L.h2_ntt_scaled_device(self.curve, ctypes.c_void_p(a.data_ptr()), m, self._m["omega_inv"].ctypes.data,
+                                          self.k, self._m["ifft_divisor"].ctypes.data, self._stream())
         _lib.check(st, "h2_ntt_scaled_device")
         return a
 
     def coeff_to_lagrange(self, a):
         m = self._shape(a, self.n)
-        st = self._L.h2_ntt_device(self.curve, ctypes.c_void_p(a.data_ptr()), m, self.mont(self.omega).ctypes.data, self.k,
+        st = self._L.h2_ntt_device(self.curve, ctypes.c_void_p(a.data_ptr()), m, self._m["omega"].ctypes.data, self.k,
                                    self._stream())
         _lib.check(st, "h2_ntt_device")
         return a
@@ -110,9 +114,9 @@ class EvaluationDomain:
         out = torch.zeros(a.shape[:-2] + (en, 4), dtype=torch.int64, device=a.device)
         out[..., : self.n, :] = a
         ptr = ctypes.c_void_p(out.data_ptr())
-        _lib.check(self._L.h2_poly_coset_device(self.curve, ptr, en, m, self.mont(self.g_coset).ctypes.data, self._stream()),
+        _lib.check(self._L.h2_poly_coset_device(self.curve, ptr, en, m, self._m["g_coset"].ctypes.data, self._stream()),
                    "h2_poly_coset_device")
-        _lib.check(self._L.h2_ntt_device(self.curve, ptr, m, self.mont(self.extended_omega).ctypes.data, self.extended_k,
+        _lib.check(self._L.h2_ntt_device(self.curve, ptr, m, self._m["extended_omega"].ctypes.data, self.extended_k,
                                          self._stream()), "h2_ntt_device")
         return out
 
@@ -121,10 +125,10 @@ class EvaluationDomain:
         en = 1 << self.extended_k
         m = self._shape(a, en)
         ptr = ctypes.c_void_p(a.data_ptr())
-        _lib.check(self._L.h2_ntt_scaled_device(self.curve, ptr, m, self.mont(self.extended_omega_inv).ctypes.data,
-                                                self.extended_k, self.mont(self.extended_ifft_divisor).ctypes.data,
+        _lib.check(self._L.h2_ntt_scaled_device(self.curve, ptr, m, self._m["extended_omega_inv"].ctypes.data,
+                                                self.extended_k, self._m["extended_ifft_divisor"].ctypes.data,
                                                 self._stream()), "h2_ntt_scaled_device")
-        _lib.check(self._L.h2_poly_coset_device(self.curve, ptr, en, m, self.mont(self.g_coset_inv).ctypes.data,
+        _lib.check(self._L.h2_poly_coset_device(self.curve, ptr, en, m, self._m["g_coset_inv"].ctypes.data,
                                                 self._stream()), "h2_poly_coset_device")
         return a[..., : self.n * self.quotient_poly_degree, :].contiguous()
 
@@ -150,7 +154,8 @@ class EvaluationDomain:
     def scale(self, a, c):
         n = a.shape[-2]
         m = a.numel() // (4 * n)
-        st = self._L.h2_poly_scale_device(self.curve, ctypes.c_void_p(a.data_ptr()), n, m, self.mont(c).ctypes.data,
+        cm = self.mont(c)
+        st = self._L.h2_poly_scale_device(self.curve, ctypes.c_void_p(a.data_ptr()), n, m, cm.ctypes.data,
                                           self._stream())
         _lib.check(st, "h2_poly_scale_device")
         return a

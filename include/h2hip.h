@@ -21,7 +21,8 @@
  *   Jacobian point = x || y || z, identity has z = 0                               96 bytes
  * All functions return 0 on success or a negative h2_status_t; they never abort or throw
  * across the ABI (the reference panics on length mismatch; here that is H2_EINVAL).
- * Calls are thread-safe and serialise on the device's internal stream.  One process drives
+ * Calls are thread-safe and serialise on the device's internal stream (a blocking stream: work enqueued
+ * with stream = NULL is ordered against the legacy null stream, PyTorch's default).  One process drives
  * one GPU (h2_init(device)); multi-GPU column sharding is done by the host layer over
  * torch.distributed/RCCL, one rank per GPU.
  */
