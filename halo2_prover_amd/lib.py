@@ -85,6 +85,12 @@ def load():
             raise ImportError(
                 "halo2_prover_amd: %s not found -- build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.  When PyTorch is installed, load it
+        # first so that libh2hip.so binds to the same copy (two runtimes in one process do not see the GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # the C ABI itself does not need PyTorch (e.g. a Rust host)
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in list(SYMBOLS.items()) + list(SELFTEST_SYMBOLS.items()):
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

@@ -1,0 +1,156 @@
+"""GPU: BASELINE.json's full sizes through size-independent properties (the oracle is too slow there), and the
+golden params fixtures through ParamsKZG.
+
+* MSM n = 2^20 (config 4): linearity  MSM(a) + MSM(b) = MSM(a + b)  and  MSM(c, c, ..., c) = c * sum(P_i)
+  with the sum obtained from an MSM of ones; bases from h2_srs_generate (itself checked against the oracle at
+  n = 2^8, whose [s^i]G is pinned by the params sha256).
+* NTT n = 2^22 (three passes) and the 64-column batch shape of config 5 at reduced n: iNTT(NTT(a)) = n a,
+  linearity, and A[0] = sum(a).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def L(f, v):
+    return np.array(f.limbs(v), dtype=np.uint64)
+
+
+def srs(h2, curve, s, n):
+    import torch
+    f = R.CURVES[curve].scalar
+    buf = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    s_m = L(f, s)
+    st = h2.load().h2_srs_generate(h2.CURVES[curve], s_m.ctypes.data, n, ctypes.c_void_p(buf.data_ptr()), None)
+    assert st == 0
+    torch.cuda.synchronize()
+    return buf
+
+
+def test_srs_generate_matches_pinned_powers(h2):
+    n = 256
+    f = R.BN_FR
+    s = R.SurveyStream().fr_random(f)      # the scalar behind the pinned params files
+    got = srs(h2, "bn254", s, n).cpu().numpy().view(np.uint64)
+    want = O.to_affine(0, O.powers_of_s(0, L(f, s), n)).reshape(n, 8)
+    assert np.array_equal(got, want)
+    data = open(os.path.join(GOLDEN, "params_k6.bin"), "rb").read()
+    g = np.frombuffer(data, dtype=np.uint64, count=8 * 64, offset=4).reshape(64, 8)
+    assert np.array_equal(got[:64], g)     # == the g vector of the reference's own params file (sha256-pinned)
+
+
+def test_params_kzg_on_golden_files(h2):
+    """ParamsKZG.read/write round trip and commit / commit_lagrange on the pinned k = 4, 6 params."""
+    f = R.BN_FR
+    for k in (4, 6):
+        data = open(os.path.join(GOLDEN, "params_k%d.bin" % k), "rb").read()
+        params = h2.ParamsKZG.read(data)
+        assert params.k == k and params.write() == data
+        n = 1 << k
+        ones = np.tile(L(f, 1), (n, 1))
+        # sum_i g_lagrange[i] = g[0]  
+        assert np.array_equal(O.to_affine(0, params.commit_lagrange(ones)), params.g[0])
+        # commit(e_i) = g[i]; commit_lagrange(w^(-ij)/n) = g_lagrange row relation
+        for i in (0, 1, n - 1):
+            e = np.zeros((n, 4), dtype=np.uint64)
+            e[i] = L(f, 1)
+            assert np.array_equal(O.to_affine(0, params.commit(e)), params.g[i])
+        winv, ninv = pow(f.omega(k), -1, f.p), pow(n, -1, f.p)
+        i = 3
+        coeffs = np.array([f.limbs(pow(winv, i * j, f.p) * ninv % f.p) for j in range(n)], dtype=np.uint64)
+        assert np.array_equal(O.to_affine(0, params.commit(coeffs)), params.g_lagrange[i])
+        # a batch of columns in one launch, against the oracle
+        cols = [O.synth_scalars(1, 0x48324D5300000300 + c, n).reshape(n, 4) for c in range(4)]
+        got = params.commit_many(cols, lagrange=True)
+        for c, col in enumerate(cols):
+            assert np.array_equal(got[c], O.to_affine(0, O.best_multiexp(0, col, params.g_lagrange)))
+        with pytest.raises(ValueError):
+            params.commit(ones[:-1])
+    with pytest.raises(ValueError):
+        h2.ParamsKZG.read(data[:-1])
+
+
+@pytest.mark.parametrize("curve", ["pallas", "bn254"])
+def test_msm_2_20_properties(h2, curve):
+    import torch
+    cid = O.CURVE_IDS[curve]
+    fs = R.CURVES[curve].scalar
+    n = 1 << 20
+    bases = h2.Bases.from_device(curve, srs(h2, curve, 0xABCDEF0123, n).data_ptr(), n)
+    try:
+        assert bases.plan()["window_bits"] == 16
+        a = O.synth_scalars(O.CURVE_SCALAR_FIELD[cid], 0x48324D5300000401, n).reshape(n, 4)
+        b = O.synth_scalars(O.CURVE_SCALAR_FIELD[cid], 0x48324D5300000402, n).reshape(n, 4)
+        dev = torch.from_numpy(np.stack([a, b]).view(np.int64)).cuda()
+        # a + b on the device (pointwise add through the ABI), so the sum column never leaves HBM
+        s_dev = dev[0].clone()
+        st = h2.load().h2_poly_pointwise_device(cid, 0, ctypes.c_void_p(s_dev.data_ptr()), ctypes.c_void_p(dev[1].data_ptr()),
+                                                n, None)
+        assert st == 0
+        cols = torch.stack([dev[0], dev[1], s_dev]).contiguous()
+        out = torch.zeros((3, 12), dtype=torch.int64, device="cuda")
+        bases.msm_device(cols.data_ptr(), n, 3, out.data_ptr())
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        pa, pb, pab = res[0], res[1], res[2]
+        assert np.array_equal(O.to_affine(cid, O.jac_add(cid, pa, pb)), O.to_affine(cid, pab))
+        assert O.is_on_curve(cid, O.to_affine(cid, pab)) and O.to_affine(cid, pab).any()
+        # constant column: MSM(c, ..., c) = c * MSM(1, ..., 1)
+        c = 0x1D2C3B4A5F6E7788990011223344556677
+        ones = np.tile(L(fs, 1), (n, 1))
+        consts = np.tile(L(fs, c), (n, 1))
+        p1 = O.to_affine(cid, bases.msm(ones))
+        pc = O.to_affine(cid, bases.msm(consts))
+        assert np.array_equal(O.to_affine(cid, O.scalar_mul(cid, L(fs, c), p1)), pc)
+    finally:
+        bases.release()
+
+
+def test_ntt_2_22_and_batch_properties(h2):
+    import torch
+    curve = "pallas"
+    cid = O.CURVE_IDS[curve]
+    f = R.CURVES[curve].scalar
+    fid = O.CURVE_SCALAR_FIELD[cid]
+    for log_n, m in ((22, 1), (16, 64)):
+        n = 1 << log_n
+        a = O.synth_scalars(fid, 0x48324D5300000500 + log_n, n * m).reshape(m, n, 4)
+        w, winv = L(f, f.omega(log_n)), L(f, pow(f.omega(log_n), -1, f.p))
+        d = torch.from_numpy(a.view(np.int64)).cuda()
+        h2.ntt_device(d.data_ptr(), m, w, log_n, curve)
+        torch.cuda.synchronize()
+        fwd = d.cpu().numpy().view(np.uint64).reshape(m, n, 4)
+        # A[0] = sum_j a[j]  (column 0 and the last column)
+        for col in (0, m - 1):
+            # exact sum of the column by pairwise halving with the device's pointwise add
+            s = torch.from_numpy(a[col].view(np.int64)).cuda()
+            length = n
+            while length > 1:
+                half = length // 2
+                lo, hi = s[:half].contiguous(), s[half:length].contiguous()
+                assert h2.load().h2_poly_pointwise_device(cid, 0, ctypes.c_void_p(lo.data_ptr()),
+                                                          ctypes.c_void_p(hi.data_ptr()), half, None) == 0
+                s, length = lo, half
+            torch.cuda.synchronize()
+            assert np.array_equal(s[0].cpu().numpy().view(np.uint64), fwd[col][0])
+        # round trip: iNTT(NTT(a)) = n * a
+        h2.ntt_device(d.data_ptr(), m, winv, log_n, curve)
+        torch.cuda.synchronize()
+        back = d.cpu().numpy().view(np.uint64).reshape(m, n, 4)
+        sample = np.random.RandomState(1).randint(0, n, size=64)
+        n_m = L(f, n)
+        for col in (0, m - 1):
+            want = O.field_mul_many(fid, a[col][sample].reshape(-1), np.tile(n_m, 64)).reshape(64, 4)
+            assert np.array_equal(back[col][sample], want)
+        # one column of the batch against the oracle outright (n = 2^16), and spot columns equal single-column runs
+        if log_n == 16:
+            want = O.best_fft(fid, a[5], w, log_n, threads=8).reshape(n, 4)
+            assert np.array_equal(fwd[5], want)
