@@ -4,12 +4,14 @@ TEST INFRASTRUCTURE ONLY (never imported by halo2_prover_amd/).  It restates, fr
 what `halo2_proofs::plonk::{keygen_vk, keygen_pk, create_proof}` @6b43b6b do when the reference calls them at
 /root/reference/circuits/src/utils.rs:63-70 (keygen) and :95-123 (generate_proof_with_instance, GWC), for the
 arithmetic circuit of /root/reference/circuits/src/arithmetic_circuit.rs (configure :187-230, synthesize
-:232-267).  Everything is plain Python integers and coefficient lists; it is meant for k = 4..6.
+:232-267) and the Poseidon circuit of poseidon_circuit.rs (:68-123, Pow5 chip).  Everything is plain Python
+integers and coefficient lists; it is meant for k = 4..6.
 
-Pins (tests/test_proof_pins.py): under the deterministic RNG stream of SURVEY.md App. B.2 the proof of
-`{"x":6,"y":9,"constant":7,"z":2923}` at k = 4 must reproduce the challenge checkpoints of App. B.5 and the
-proof sha256 of App. B.2.  The verifying-key digest `transcript_repr` is taken from App. A.6 (it is Blake2b over
-the Rust `{:?}` rendering of the pinned vk; re-deriving that string is not attempted here).
+Pins (tests/test_proof_pins.py): under the deterministic RNG stream of SURVEY.md App. B.2 the proofs of
+`{"x":6,"y":9,"constant":7,"z":2923}` at k = 4 and of Poseidon([1, 2]) at k = 6 reproduce the challenge
+checkpoints of App. B.5 and the proof sha256 values of App. B.2, and the verifying-key digests
+`transcript_repr` (Blake2b over the Rust `{:?}` rendering of the pinned vk, re-derived here) equal the values
+recorded in App. A.6.
 
 The MSM and NTT calls go through a small backend object so that the same prover logic can run on the CPU oracle
 (this file) or on the GPU library (halo2_prover_amd/prover.py uses its own copy of the host logic).
@@ -156,12 +158,88 @@ class ChaCha20Rng:
         return v % P
 
 
-# ---------------------------------------------------------------- circuit description -----------------------
-class ArithmeticCircuit:
+# ---------------------------------------------------------------- expressions -------------------------------
+# halo2's Expression tree as nested tuples; the Rust operators map as SURVEY.md App. A.6 records:
+# a + b -> Sum, a - b -> Sum(a, Negated(b)), a * b -> Product, expr * F -> Scaled, -a -> Negated.
+def Const(v): return ("const", v % P)
+def Adv(qi, col, rot): return ("advice", qi, col, rot)
+def Fix(qi, col, rot): return ("fixed", qi, col, rot)
+def Inst(qi, col, rot): return ("instance", qi, col, rot)
+def Neg(a): return ("neg", a)
+def Sum(a, b): return ("sum", a, b)
+def Sub(a, b): return ("sum", a, ("neg", b))
+def Prod(a, b): return ("prod", a, b)
+def Scaled(a, c): return ("scaled", a, c % P)
+
+
+def expr_debug(e):
+    """Rust `{:?}` of a halo2 Expression (non-pretty)"""
+    t = e[0]
+    if t == "const":
+        return "Constant(0x%064x)" % e[1]
+    if t in ("advice", "fixed", "instance"):
+        return "%s { query_index: %d, column_index: %d, rotation: Rotation(%d) }" % (t.capitalize(), e[1], e[2], e[3])
+    if t == "neg":
+        return "Negated(%s)" % expr_debug(e[1])
+    if t == "sum":
+        return "Sum(%s, %s)" % (expr_debug(e[1]), expr_debug(e[2]))
+    if t == "prod":
+        return "Product(%s, %s)" % (expr_debug(e[1]), expr_debug(e[2]))
+    if t == "scaled":
+        return "Scaled(%s, 0x%064x)" % (expr_debug(e[1]), e[2])
+    raise ValueError(t)
+
+
+def expr_eval_poly(e, cols, omega, cache):
+    """evaluate an expression on coefficient-form column polynomials; cols[kind][column] -> coefficients"""
+    if e in cache:
+        return cache[e]
+    t = e[0]
+    if t == "const":
+        r = [e[1]]
+    elif t in ("advice", "fixed", "instance"):
+        base = cols[t][e[2]]
+        r = base if e[3] == 0 else protate(base, pow(omega, e[3], P))
+    elif t == "neg":
+        r = pscale(expr_eval_poly(e[1], cols, omega, cache), P - 1)
+    elif t == "sum":
+        r = padd(expr_eval_poly(e[1], cols, omega, cache), expr_eval_poly(e[2], cols, omega, cache))
+    elif t == "prod":
+        r = pmul(expr_eval_poly(e[1], cols, omega, cache), expr_eval_poly(e[2], cols, omega, cache))
+    elif t == "scaled":
+        r = pscale(expr_eval_poly(e[1], cols, omega, cache), e[2])
+    else:
+        raise ValueError(t)
+    cache[e] = r
+    return r
+
+
+# ---------------------------------------------------------------- circuit descriptions ----------------------
+class Circuit:
+    """What keygen / create_proof need to know about a circuit (after selector compression)."""
+    name = ""
+    num_advice = num_fixed = num_instance = num_selectors = 0
+    degree = 3
+    perm_columns = []            # ("advice"|"fixed"|"instance", index) in enable_equality order
+    advice_queries = []          # (column, rotation) in first-use order
+    fixed_queries = []
+    instance_queries = [(0, 0)]
+    constants = []               # fixed columns enabled as constants columns
+    gates = []                   # gate polynomials (expression trees), cs.gates order
+
+    def blinding_factors(self):
+        per_col = {}
+        for col, rot in self.advice_queries:
+            per_col.setdefault(col, set()).add(rot)
+        return max(3, max(len(v) for v in per_col.values())) + 2
+
+
+class ArithmeticCircuit(Circuit):
     """/root/reference/circuits/src/arithmetic_circuit.rs: 3 advice (l, r, o), 5 fixed (sm, sl, sr, so, sc in
     creation order :196-200), 1 instance column; one degree-3 gate; equality on l, r, o, PI."""
 
-    num_advice, num_fixed, num_instance = 3, 5, 1
+    name = "arithmetic"
+    num_advice, num_fixed, num_instance, num_selectors = 3, 5, 1, 0
     degree = 3                               # max(gate degree 3, permutation argument 3)
     SM, SL, SR, SO, SC = 0, 1, 2, 3, 4
     # permutation columns in enable_equality order (:192-194, :203)
@@ -171,9 +249,10 @@ class ArithmeticCircuit:
 
     def __init__(self, x, y, constant):
         self.x, self.y, self.constant = x, y, constant
-
-    def blinding_factors(self):
-        return max(3, 1) + 2                 # max distinct queries of any advice column is 1
+        l, r, o = Adv(0, 0, 0), Adv(1, 1, 0), Adv(2, 2, 0)
+        sl, sr, so, sm, sc = Fix(0, 1, 0), Fix(1, 2, 0), Fix(2, 3, 0), Fix(3, 0, 0), Fix(4, 4, 0)
+        # :216  l*sl + r*sr + l*r*sm + (o*so*(-1)) + sc
+        self.gates = [Sum(Sum(Sum(Sum(Prod(l, sl), Prod(r, sr)), Prod(Prod(l, r), sm)), Scaled(Prod(o, so), P - 1)), sc)]
 
     def fixed_columns(self, n):
         f = [[0] * n for _ in range(5)]
@@ -197,14 +276,204 @@ class ArithmeticCircuit:
         return [(A(0, 0), A(1, 0)), (A(0, 1), A(1, 1)), (A(2, 0), A(0, 2)), (A(2, 1), A(1, 2)),
                 (A(2, 2), A(0, 3)), (A(1, 3), I(0)), (A(2, 3), I(1))]
 
-    def gate_polys(self, adv, fix, inst, rot):
-        """gate polynomials on coefficient-form columns (:216): l*sl + r*sr + l*r*sm + (o*so*(-1)) + sc"""
-        l, r, o = adv
-        sm, sl, sr, so, sc = fix
-        t = padd(pmul(l, sl), pmul(r, sr))
-        t = padd(t, pmul(pmul(l, r), sm))
-        t = padd(t, pscale(pmul(o, so), P - 1))
-        return [padd(t, sc)]
+
+def poseidon_mds_inverse(field, t, r_f, r_p):
+    """mds.rs:5-102: Cauchy matrix and its closed-form inverse, from the same Grain stream"""
+    p = field.p
+    g = R.Grain(field, t, r_f, r_p)
+    rcs = [[g.next_field_element() for _ in range(t)] for _ in range(r_f + r_p)]
+    while True:
+        vals = [g.next_without_rejection() for _ in range(2 * t)]
+        if len(set(vals)) == len(vals):
+            break
+    xs, ys = vals[:t], vals[t:]
+    mds = [[pow(xs[i] + ys[j], -1, p) for j in range(t)] for i in range(t)]
+
+    def lag(pts, j, x):
+        acc = 1
+        for m, xm in enumerate(pts):
+            if m != j:
+                acc = acc * (x - xm) % p * pow(pts[j] - xm, -1, p) % p
+        return acc
+
+    nys = [(-y) % p for y in ys]
+    minv = [[(xs[j] - nys[i]) * lag(xs, j, nys[i]) % p * lag(nys, i, xs[j]) % p for j in range(t)] for i in range(t)]
+    for i in range(t):                       # sanity: it is the inverse
+        for j in range(t):
+            assert sum(mds[i][k] * minv[k][j] for k in range(t)) % p == (1 if i == j else 0)
+    return rcs, mds, minv
+
+
+class PoseidonCircuit(Circuit):
+    """/root/reference/circuits/src/poseidon_circuit.rs (configure :68-89, synthesize :92-123) with the Pow5 chip
+    (same structure as the vendored /root/reference/circuits/src/poseidon/pow5.rs:58-206, 230-272, 280-389,
+    433-592): WIDTH 3, RATE 2, L 2, R_F 8, R_P 60 over bn256::Fr.  Columns: advice state0..2 = 0..2,
+    partial_sbox = 3; fixed rc_a = 0..2, rc_b = 3..5, selector columns s_full, s_partial, s_pad_and_add = 6..8
+    (each selector gets its own fixed column: the degree-6 gates leave no room to combine)."""
+
+    name = "poseidon"
+    num_advice, num_fixed, num_instance, num_selectors = 4, 9, 1, 3
+    degree = 6
+    WIDTH, RATE, R_F, R_P = 3, 2, 8, 60
+    perm_columns = [("instance", 0), ("fixed", 3), ("advice", 0), ("advice", 1), ("advice", 2), ("fixed", 4), ("fixed", 5)]
+    advice_queries = [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (3, 0), (2, -1), (0, -1), (1, -1)]
+    fixed_queries = [(3, 0), (4, 0), (5, 0), (0, 0), (1, 0), (2, 0), (6, 0), (7, 0), (8, 0)]
+    constants = [3]
+
+    def __init__(self, message):
+        self.message = [m % P for m in message]
+        self.rcs, self.mds, self.minv = poseidon_mds_inverse(FR, 3, self.R_F, self.R_P)
+        mds, minv = self.mds, self.minv
+        s_cur = [Adv(i, i, 0) for i in range(3)]
+        s_next = [Adv(3 + i, i, 1) for i in range(3)]
+        ps = Adv(6, 3, 0)
+        s_prev = [Adv(8, 0, -1), Adv(9, 1, -1), Adv(7, 2, -1)]
+        rc_b = [Fix(i, 3 + i, 0) for i in range(3)]
+        rc_a = [Fix(3 + i, i, 0) for i in range(3)]
+        s_full, s_partial, s_pad = Fix(6, 6, 0), Fix(7, 7, 0), Fix(8, 8, 0)
+
+        def pow5(v):
+            v2 = Prod(v, v)
+            return Prod(Prod(v2, v2), v)
+
+        gates = []
+        for nxt in range(3):                                   # "full round"  pow5.rs:95-115
+            terms = [Scaled(pow5(Sum(s_cur[i], rc_a[i])), mds[nxt][i]) for i in range(3)]
+            gates.append(Prod(s_full, Sub(Sum(Sum(terms[0], terms[1]), terms[2]), s_next[nxt])))
+
+        def mid(i):
+            acc = Scaled(ps, mds[i][0])
+            for cidx in (1, 2):
+                acc = Sum(acc, Scaled(Sum(s_cur[cidx], rc_a[cidx]), mds[i][cidx]))
+            return acc
+
+        def nxt(i):
+            return Sum(Sum(Scaled(s_next[0], minv[i][0]), Scaled(s_next[1], minv[i][1])), Scaled(s_next[2], minv[i][2]))
+
+        partial = [Sub(pow5(Sum(s_cur[0], rc_a[0])), ps),      # "partial rounds"  pow5.rs:117-161
+                   Sub(pow5(Sum(mid(0), rc_b[0])), nxt(0))]
+        for i in (1, 2):
+            partial.append(Sub(Sum(mid(i), rc_b[i]), nxt(i)))
+        gates += [Prod(s_partial, g) for g in partial]
+        pad = [Sub(Sum(s_prev[i], s_cur[i]), s_next[i]) for i in (0, 1)]   # "pad-and-add"  pow5.rs:163-187
+        pad.append(Sub(s_prev[2], s_next[2]))
+        gates += [Prod(s_pad, g) for g in pad]
+        self.gates = gates
+
+    # ---- layout: row 0 message, row 1 initial state, rows 2-4 pad-and-add, rows 5-43 permutation -------------
+    def _rounds(self):
+        """advice rows of the permutation region (offsets 0..38) and the partial_sbox column"""
+        rcs, mds = self.rcs, self.mds
+        cap = (2 << 64) % P                                    # ConstantLength<2>: L * 2^64
+        state = [self.message[0], self.message[1], cap]
+        rows, sbox = [list(state)], {}
+
+        def mix(v):
+            return [sum(mds[i][j] * v[j] for j in range(3)) % P for i in range(3)]
+
+        def full(st, rnd):
+            return mix([pow((st[i] + rcs[rnd][i]) % P, 5, P) for i in range(3)])
+
+        for r in range(4):
+            state = full(state, r)
+            rows.append(list(state))
+        for r in range(30):
+            rnd = 4 + 2 * r
+            r0 = [pow((state[0] + rcs[rnd][0]) % P, 5, P)] + [(state[i] + rcs[rnd][i]) % P for i in (1, 2)]
+            sbox[4 + r] = r0[0]
+            midv = mix(r0)
+            r1 = [pow((midv[0] + rcs[rnd + 1][0]) % P, 5, P)] + [(midv[i] + rcs[rnd + 1][i]) % P for i in (1, 2)]
+            state = mix(r1)
+            rows.append(list(state))
+        for r in range(4):
+            state = full(state, 4 + 60 + r)
+            rows.append(list(state))
+        return rows, sbox
+
+    def output(self):
+        return self._rounds()[0][-1][0]
+
+    def witness(self, n):
+        adv = [[0] * n for _ in range(4)]
+        m0, m1 = self.message
+        cap = (2 << 64) % P
+        adv[0][0], adv[1][0] = m0, m1                          # load message
+        adv[0][1], adv[1][1], adv[2][1] = 0, 0, cap           # initial state
+        adv[0][2], adv[1][2], adv[2][2] = 0, 0, cap           # add input: copy of the state
+        adv[0][3], adv[1][3] = m0, m1                          #            the input words
+        adv[0][4], adv[1][4], adv[2][4] = m0, m1, cap         #            state + input
+        rows, sbox = self._rounds()
+        for off, st in enumerate(rows):
+            for i in range(3):
+                adv[i][5 + off] = st[i]
+        for off, v in sbox.items():
+            adv[3][5 + off] = v
+        return adv
+
+    def fixed_columns(self, n):
+        f = [[0] * n for _ in range(9)]
+        rcs = self.rcs
+        f[3][0], f[3][1], f[3][2] = 0, 0, (2 << 64) % P       # constants of the "initial state" region in rc_b0
+        f[8][3] = 1                                            # s_pad_and_add
+        for r in range(4):                                     # first full rounds: offsets 0..3
+            for i in range(3):
+                f[i][5 + r] = rcs[r][i]
+            f[6][5 + r] = 1
+        for r in range(30):                                    # partial rounds: offsets 4..33
+            off, rnd = 4 + r, 4 + 2 * r
+            for i in range(3):
+                f[i][5 + off] = rcs[rnd][i]
+                f[3 + i][5 + off] = rcs[rnd + 1][i]
+            f[7][5 + off] = 1
+        for r in range(4):                                     # last full rounds: offsets 34..37
+            off, rnd = 34 + r, 64 + r
+            for i in range(3):
+                f[i][5 + off] = rcs[rnd][i]
+            f[6][5 + off] = 1
+        return f
+
+    def copies(self):
+        A = lambda c, r: (("advice", c), r)  # noqa: E731
+        out = [((("fixed", 3), i), A(i, 1)) for i in range(3)]           # constants -> initial state cells
+        out += [(A(i, 2), A(i, 1)) for i in range(3)]                    # add input: load state
+        out += [(A(i, 3), A(i, 0)) for i in range(2)]                    #            load input words
+        out += [(A(i, 5), A(i, 4)) for i in range(3)]                    # permute: load state
+        out.append((A(0, 43), (("instance", 0), 0)))                     # constrain_instance(output)
+        return out
+
+
+def vk_debug_string(circuit, k, fixed_commitments, sigma_commitments):
+    """format!("{:?}", vk.pinned()) of halo2_proofs @6b43b6b"""
+    def col(kind, i):
+        return "Column { index: %d, column_type: %s }" % (i, kind.capitalize())
+
+    def pt(q):
+        return "Infinity" if q is None else "(0x%064x, 0x%064x)" % q
+
+    ext_k = k
+    while (1 << ext_k) < (1 << k) * (circuit.degree - 1):
+        ext_k += 1
+    s = ('PinnedVerificationKey { base_modulus: "0x%x", scalar_modulus: "0x%x", domain: PinnedEvaluationDomain '
+         '{ k: %d, extended_k: %d, omega: 0x%064x }, ' % (R.P_BN, R.R_BN, k, ext_k, FR.omega(k)))
+    s += ("cs: PinnedConstraintSystem { num_fixed_columns: %d, num_advice_columns: %d, num_instance_columns: %d, "
+          "num_selectors: %d, gates: [%s], " % (circuit.num_fixed, circuit.num_advice, circuit.num_instance,
+                                                circuit.num_selectors, ", ".join(expr_debug(g) for g in circuit.gates)))
+    s += "advice_queries: [%s], " % ", ".join("(%s, Rotation(%d))" % (col("advice", c), r) for c, r in circuit.advice_queries)
+    s += "instance_queries: [%s], " % ", ".join("(%s, Rotation(%d))" % (col("instance", c), r) for c, r in circuit.instance_queries)
+    s += "fixed_queries: [%s], " % ", ".join("(%s, Rotation(%d))" % (col("fixed", c), r) for c, r in circuit.fixed_queries)
+    s += "permutation: Argument { columns: [%s] }, " % ", ".join(col(kd, i) for kd, i in circuit.perm_columns)
+    s += "lookups: [], constants: [%s], minimum_degree: None }, " % ", ".join(col("fixed", c) for c in circuit.constants)
+    s += "fixed_commitments: [%s], " % ", ".join(pt(q) for q in fixed_commitments)
+    s += "permutation: VerifyingKey { commitments: [%s] } }" % ", ".join(pt(q) for q in sigma_commitments)
+    return s
+
+
+def vk_transcript_repr(circuit, k, fixed_commitments, sigma_commitments):
+    s = vk_debug_string(circuit, k, fixed_commitments, sigma_commitments)
+    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+    h.update(len(s).to_bytes(8, "little"))
+    h.update(s.encode())
+    return int.from_bytes(h.digest(), "little") % P
 
 
 # ---------------------------------------------------------------- CPU backend --------------------------------
@@ -272,11 +541,10 @@ def permutation_mapping(circuit, n):
 
 
 class ProvingKey:
-    def __init__(self, circuit, backend, transcript_repr):
+    def __init__(self, circuit, backend, transcript_repr=None):
         n, k = backend.n, backend.k
         self.circuit, self.n, self.k = circuit, n, k
         self.omega = FR.omega(k)
-        self.transcript_repr = transcript_repr
         self.fixed_values = circuit.fixed_columns(n)
         self.fixed_polys = [backend.lagrange_to_coeff(v) for v in self.fixed_values]
         self.fixed_commitments = [backend.commit_lagrange(v) for v in self.fixed_values]
@@ -285,6 +553,10 @@ class ProvingKey:
                               for i in range(n)] for j in range(len(circuit.perm_columns))]
         self.sigma_polys = [backend.lagrange_to_coeff(v) for v in self.sigma_values]
         self.sigma_commitments = [backend.commit_lagrange(v) for v in self.sigma_values]
+        derived = vk_transcript_repr(circuit, k, self.fixed_commitments, self.sigma_commitments)
+        if transcript_repr is not None:
+            assert derived == transcript_repr, "derived vk transcript_repr differs from the expected value"
+        self.transcript_repr = derived
 
 
 # ---------------------------------------------------------------- create_proof (GWC) -------------------------
@@ -377,7 +649,9 @@ def create_proof(pk, backend, instances, rng, trace=None):
     l_last = lagrange_basis([n - bf - 1])
     l_blind = lagrange_basis(range(n - bf, n))
     l_active = psub(psub([1], l_last), l_blind)
-    terms = list(c.gate_polys(adv_polys, fixed_polys, inst_polys, None))
+    cache = {}
+    cols = {"advice": adv_polys, "fixed": fixed_polys, "instance": inst_polys}
+    terms = [expr_eval_poly(g, cols, omega, cache) for g in c.gates]
     terms.append(pmul(l0, psub([1], z_polys[0])))
     zl = z_polys[-1]
     terms.append(pmul(l_last, psub(pmul(zl, zl), zl)))
@@ -451,7 +725,10 @@ def create_proof(pk, backend, instances, rng, trace=None):
     return tr.proof
 
 
-# transcript_repr of the pinned verifying keys under the SURVEY App. B.2 stream
+# transcript_repr of the pinned verifying keys under the SURVEY App. B.2 stream, as recorded in SURVEY.md
+# App. A.6 from the reference's build; vk_transcript_repr() must re-derive them
 TRANSCRIPT_REPR = {
     ("arithmetic", 4): 0x29FDBC4FAA50E4E635114C86B4655A8CC4C5B56751D66E7F06C91C80076930F9,
+    ("poseidon", 6): 0x0394952BB11B51B764C54781C76A552834CD31144A91BC35FDAC9CDD15070A39,
+    ("collatz", 10): 0x174D961F4BE70218C76F49111B0E742F0EC7583D402762C15220F90E82809AB5,
 }

@@ -29,7 +29,10 @@ PROOF_SHA256_K4 = "31d427b9666777794f4a126fbde11584f28748005a32dcaf27e40974f3866
 def test_arithmetic_k4_proof_matches_reference_record():
     params = open(os.path.join(GOLDEN, "params_k4.bin"), "rb").read()
     be = H.OracleBackend(params)
-    pk = H.ProvingKey(H.ArithmeticCircuit(6, 9, 7), be, H.TRANSCRIPT_REPR[("arithmetic", 4)])
+    pk = H.ProvingKey(H.ArithmeticCircuit(6, 9, 7), be)
+    # the vk digest is DERIVED (Blake2b over the Rust {:?} rendering of the pinned vk) and must equal the value
+    # recorded from the reference's build: this also pins the 5 fixed and 4 permutation commitments of keygen
+    assert pk.transcript_repr == H.TRANSCRIPT_REPR[("arithmetic", 4)]
     # keygen facts of SURVEY.md App. A.6: the all-zero fixed column sc commits to the identity
     assert pk.fixed_commitments[H.ArithmeticCircuit.SC] is None
     assert all(pt is not None and R.BN254.is_on_curve(pt) for pt in pk.sigma_commitments)
@@ -54,6 +57,40 @@ def test_golden_proof_file_is_the_pinned_bytes():
 def test_a_different_witness_changes_the_proof_but_not_its_shape():
     params = open(os.path.join(GOLDEN, "params_k4.bin"), "rb").read()
     be = H.OracleBackend(params)
-    pk = H.ProvingKey(H.ArithmeticCircuit(3, 5, 11), be, H.TRANSCRIPT_REPR[("arithmetic", 4)])
+    pk = H.ProvingKey(H.ArithmeticCircuit(3, 5, 11), be)
     proof = H.create_proof(pk, be, [[11, 3 * 3 * 5 * 5 + 11]], R.SurveyStream(start=8))
     assert len(proof) == 1184 and hashlib.sha256(proof).hexdigest() != PROOF_SHA256_K4
+
+
+CHALLENGES_POSEIDON_K6 = {
+    "theta": 0x0B3C600455604EDA16B5DD3BDE867A7959D86F521C9BA096C0573C726193023D,
+    "beta": 0x0208C22065465C8B4FF9ECF3AEBD94F8830ECEAB6469DF96ADCA59D852AD04BB,
+    "gamma": 0x2DA14E6EC8FD961A1C70496B0438CD7CDE6CB376B6B3CA7D89AC16EECE15830D,
+    "y": 0x02829BCBB0AC70200F1DEC238DEE474499B2BE901A839A5042D66CA4D97B3DF3,
+    "x": 0x122555C65F6F0CB889DD51420A47AB236450C7EAF7F7A253ED11ECB1BF2E109D,
+    "v": 0x1DF4C5795BEAE4379F05C98DE19DE324BF5E5DEAB457E5A9D7AC646F788D9D75,
+}
+PROOF_SHA256_POSEIDON_K6 = "6d235bf4637e1dce12559c44eaf77812bae2746d78331db3850e16b26234e63e"
+
+
+def test_poseidon_k6_proof_matches_reference_record():
+    """circuit 2 of wasm_generate_proof (wasm.rs:98-118): Poseidon hash of [1, 2] over bn256::Fr, Pow5 chip,
+    k = 6: vk digest (a 19,935-character {:?} string), the six challenges and the 1536-byte proof."""
+    params = open(os.path.join(GOLDEN, "params_k6.bin"), "rb").read()
+    be = H.OracleBackend(params)
+    circuit = H.PoseidonCircuit([1, 2])
+    assert circuit.output() == 0x152E960B5C9C8A624B2CDF4855250E8A54EE074254281310DC4A9704F78C1917
+    pk = H.ProvingKey(circuit, be)
+    assert len(H.vk_debug_string(circuit, 6, pk.fixed_commitments, pk.sigma_commitments)) == 19935
+    assert pk.transcript_repr == H.TRANSCRIPT_REPR[("poseidon", 6)]
+    rng = R.SurveyStream(start=8)
+    trace = {}
+    proof = H.create_proof(pk, be, [[circuit.output()]], rng, trace)
+    assert {k: trace[k] for k in CHALLENGES_POSEIDON_K6} == CHALLENGES_POSEIDON_K6
+    assert len(proof) == 1536                       # 12 + 4 points, 32 scalars (SURVEY.md App. A.4)
+    assert hashlib.sha256(proof).hexdigest() == PROOF_SHA256_POSEIDON_K6
+    assert rng.counter == 8 + 46 * 8 + 1
+    path = os.path.join(GOLDEN, "proof_poseidon_k6.bin")
+    if not os.path.exists(path):
+        open(path, "wb").write(proof)
+    assert open(path, "rb").read() == proof
