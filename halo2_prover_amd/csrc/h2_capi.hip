@@ -423,6 +423,17 @@ int h2_srs_generate(h2_curve_t curve, const uint64_t s[4], size_t n, void* d_out
   return H2_OK;
 }
 
+int h2_fixed_base_mul(h2_curve_t curve, const void* d_scalars, size_t n, void* d_out_affine, void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  const CurveOps* ops = ops_of((int)curve);
+  if (!ops || !d_scalars || !d_out_affine || n == 0 || n >= (1ull << 32)) return H2_EINVAL;
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
+  hipError_t e = ops->fixed_base_mul(d_out_affine, d_scalars, (uint32_t)n, stream);
+  if (e != hipSuccess) return dev_fail(e, "fixed_base_mul_kernel");
+  return H2_OK;
+}
+
 int h2_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_ctx.profiling = on != 0;

@@ -40,6 +40,11 @@ hipError_t srs_powers(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, 
   hipLaunchKernelGGL(srs_powers_kernel<CV>, dim3((n + 255) / 256), dim3(256), 0, s, (U128*)d_out_affine, sv, n);
   return hipGetLastError();
 }
+hipError_t fixed_base_mul(void* d_out_affine, const void* d_scalars, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(fixed_base_mul_kernel<CV>, dim3((n + 255) / 256), dim3(256), 0, s, (U128*)d_out_affine,
+                     (const U128*)d_scalars, n);
+  return hipGetLastError();
+}
 hipError_t to_jacobian(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
   hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const U128*)d_xyzz,
                      (U128*)d_out, m);
@@ -178,7 +183,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
   return carry ? -2 : 0;  // a carry out of the top window would lose value
 }
 
-const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers,
+const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers, fixed_base_mul,
                       to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
                       poly_pointwise, selftest_field, selftest_curve,
                       selftest_field_device, selftest_digits};

@@ -22,6 +22,7 @@ struct CurveOps {
                            const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s,
                            hipEvent_t ev_start, hipEvent_t ev_stop);
   hipError_t (*srs_powers)(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s);
+  hipError_t (*fixed_base_mul)(void* d_out_affine, const void* d_scalars, uint32_t n, hipStream_t s);
   hipError_t (*to_jacobian)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
   hipError_t (*to_affine)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
   // NTT over the scalar field

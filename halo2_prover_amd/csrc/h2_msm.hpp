@@ -428,6 +428,32 @@ srs_powers_kernel(U128* __restrict__ out, Fe<typename CV::Scalar> s, uint32_t n)
   fe_store<FB>(out + 4 * (size_t)i + 2, a.y);
 }
 
+// out[i] = [k_i] G for n given scalars (Montgomery form): the g_lagrange vector of ParamsKZG::new is
+// [L_i(s)] G with L_i the Lagrange basis evaluated at the toxic scalar
+template <class CV>
+__global__ void __launch_bounds__(256)
+fixed_base_mul_kernel(U128* __restrict__ out, const U128* __restrict__ scalars, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  using FS = typename CV::Scalar;
+  using FB = typename CV::Base;
+  Fe<FS> k = fe_from_mont(fe_load<FS>(scalars + 2 * (size_t)i));
+  Affine<CV> g;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    g.x.v[j] = CV::GX(j);
+    g.y.v[j] = CV::GY(j);
+  }
+  Xyzz<CV> r = Xyzz<CV>::identity();
+  for (int bit = 255; bit >= 0; bit--) {
+    r = xyzz_double(r);
+    if ((k.v[bit >> 5] >> (bit & 31)) & 1) r = xyzz_add_affine(r, g);
+  }
+  Affine<CV> a = xyzz_to_affine(r);
+  fe_store<FB>(out + 4 * (size_t)i, a.x);
+  fe_store<FB>(out + 4 * (size_t)i + 2, a.y);
+}
+
 // ---- workspace layout -------------------------------------------------------------------------
 struct MsmWorkspace {
   size_t K;             // keys = m * B

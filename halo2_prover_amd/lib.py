@@ -50,6 +50,7 @@ SYMBOLS = {
     "h2_poly_pointwise_device": (_I, [_I, _I, _P, _P, _Z, _P]),
     "h2_msm_plan": (_I, [_U64, ctypes.POINTER(MsmPlan)]),
     "h2_srs_generate": (_I, [_I, _P, _Z, _P, _P]),
+    "h2_fixed_base_mul": (_I, [_I, _P, _Z, _P, _P]),
     "h2_profile_enable": (_I, [_I]),
     "h2_profile_read": (_I, [ctypes.POINTER(Profile)]),
 }

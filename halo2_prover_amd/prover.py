@@ -1,64 +1,62 @@
-"""The reference crate's prove() surface on the GPU backend (first slice).
+"""The reference crate's prove() surface on the GPU backend.
 
-Mirrors /root/reference/circuits/src/utils.rs:
-    generate_keys(params, circuit)                                   :63-70   keygen_vk + keygen_pk
-    generate_proof_with_instance(params, pk, circuit, public_input)  :95-123  create_proof, KZG + GWC, Blake2b
-and the arithmetic circuit of /root/reference/circuits/src/arithmetic_circuit.rs (the `wasm_generate_proof`
-circuit 1, wasm.rs:90-97).  The phase order, transcript and RNG schedule follow SURVEY.md App. A.4-A.7.
+Mirrors /root/reference/circuits/src/utils.rs and wasm.rs:
+    generate_params(k)                                               utils.rs:59-61   ParamsKZG::new (setup)
+    generate_keys(params, circuit)                                   utils.rs:63-70   keygen_vk + keygen_pk
+    generate_proof_with_instance(params, pk, circuit, public_input)  utils.rs:95-123  create_proof, KZG + GWC, Blake2b
+    wasm_generate_proof(params_bytes, json, circuit_index)           wasm.rs:77-122   circuits 1 (arithmetic), 2 (Poseidon)
+for the arithmetic circuit (arithmetic_circuit.rs) and the Poseidon circuit (poseidon_circuit.rs + Pow5 chip).
+Phase order, transcript, RNG schedule, vk digest and openings follow SURVEY.md App. A.4-A.7.
 
 What runs where:
   * every commitment  -> ParamsKZG.commit_many -> h2_msm_batch            (GPU, one launch sequence per phase)
   * Lagrange -> coefficient form of every column -> h2_ntt_scaled_device  (GPU, batched)
   * the quotient h(X): coset NTTs of every column, the gate / permutation expressions with the pointwise kernels,
     divide_by_vanishing_poly, inverse coset NTT                          (GPU, EvaluationDomain)
-  * transcript hashing, Horner evaluations at x, the GWC synthetic divisions, witness synthesis and the
-    permutation union-find                                               (host Python, big integers)
+  * setup: g = [s^i]G and g_lagrange = [L_i(s)]G                         (GPU, h2_srs_generate / h2_fixed_base_mul)
+  * transcript hashing, Horner evaluations at x, the GWC synthetic divisions, witness synthesis, the permutation
+    union-find and grand products                                        (host Python, big integers)
 There is no CPU fallback for the GPU parts.  Scalars cross the boundary as 4 x u64 Montgomery limbs.
-
-The verifying-key digest `transcript_repr` is Blake2b over the Rust `{:?}` rendering of the pinned vk
-(SURVEY.md App. A.6); it is an input here (the value recorded for the pinned k = 4 params is provided) -- deriving
-the string is not implemented in this round.
 """
+import ctypes
 import hashlib
+import json
 import os
 
 import numpy as np
 
+from . import lib as _lib
 from .api import ParamsKZG
 from .domain import EvaluationDomain
 
 P = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001       # bn256::Fr modulus
 Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47       # bn256::Fq modulus
 R_P = (1 << 256) % P
-R_Q_INV = pow((1 << 256) % Q, -1, Q)
+R_P_INV = pow(R_P, -1, P)
+R_Q = (1 << 256) % Q
+R_Q_INV = pow(R_Q, -1, Q)
 GENERATOR, TWO_ADICITY = 7, 28
+ROOT_OF_UNITY = pow(GENERATOR, (P - 1) >> TWO_ADICITY, P)
 DELTA = pow(GENERATOR, 1 << TWO_ADICITY, P)
-
-# transcript_repr of the verifying key of (circuit, k) on the pinned params of tests/golden
-PINNED_TRANSCRIPT_REPR = {("arithmetic", 4): 0x29FDBC4FAA50E4E635114C86B4655A8CC4C5B56751D66E7F06C91C80076930F9}
 
 
 # ------------------------------------------------------------------------------------------- host helpers ----
 def _limbs_of(vals):
     """canonical ints -> (n, 4) uint64 Montgomery limbs"""
-    out = np.empty((len(vals), 4), dtype=np.uint64)
-    for i, v in enumerate(vals):
-        m = v % P * R_P % P
-        for j in range(4):
-            out[i, j] = (m >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
-    return out
+    buf = b"".join((v % P * R_P % P).to_bytes(32, "little") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
 
 
 def _ints_of(limbs):
-    rinv = pow(R_P, -1, P)
-    a = np.asarray(limbs, dtype=np.uint64).reshape(-1, 4)
-    return [sum(int(a[i, j]) << (64 * j) for j in range(4)) * rinv % P for i in range(a.shape[0])]
+    buf = np.ascontiguousarray(limbs, dtype=np.uint64).tobytes()
+    return [int.from_bytes(buf[i:i + 32], "little") * R_P_INV % P for i in range(0, len(buf), 32)]
 
 
 def _point_of(aff):
     """(8,) Montgomery limbs of an affine G1 point -> canonical (x, y) or None for the identity"""
-    x = sum(int(aff[j]) << (64 * j) for j in range(4)) * R_Q_INV % Q
-    y = sum(int(aff[4 + j]) << (64 * j) for j in range(4)) * R_Q_INV % Q
+    b = np.ascontiguousarray(aff, dtype=np.uint64).tobytes()
+    x = int.from_bytes(b[:32], "little") * R_Q_INV % Q
+    y = int.from_bytes(b[32:], "little") * R_Q_INV % Q
     return None if x == 0 and y == 0 else (x, y)
 
 
@@ -78,6 +76,19 @@ def _kate_division(a, z):
     return q
 
 
+def _batch_inverse(vals):
+    prefix, acc = [], 1
+    for v in vals:
+        prefix.append(acc)
+        acc = acc * v % P
+    inv = pow(acc, -1, P)
+    out = [0] * len(vals)
+    for i in range(len(vals) - 1, -1, -1):
+        out[i] = prefix[i] * inv % P
+        inv = inv * vals[i] % P
+    return out
+
+
 class OsRng:
     """rand::rngs::OsRng as the reference uses it (utils.rs:89,116): Fr::random draws 8 x next_u64."""
 
@@ -91,40 +102,36 @@ class OsRng:
         return v % P
 
 
-class _ChaCha20Rng:
-    """rand_chacha 0.3.1: 20 rounds, 64-bit block counter from 0, stream 0, key = seed."""
+def _chacha20_field_elements(seed32, count):
+    """`count` values of Fr::random(ChaCha20Rng::from_seed(seed)): rand_chacha 0.3.1 (20 rounds, 64-bit block
+    counter from 0, stream 0); one 64-byte block per element, read as a 512-bit little-endian integer mod r.
+    All blocks are generated at once with numpy."""
+    key = np.frombuffer(seed32, dtype="<u4").astype(np.uint32)
+    s = np.zeros((16, count), dtype=np.uint32)
+    s[0], s[1], s[2], s[3] = 0x61707865, 0x3320646E, 0x79622D32, 0x6B206574
+    for i in range(8):
+        s[4 + i] = key[i]
+    ctr = np.arange(count, dtype=np.uint64)
+    s[12] = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    s[13] = (ctr >> np.uint64(32)).astype(np.uint32)
+    init = s.copy()
 
-    def __init__(self, seed32):
-        self.key = [int.from_bytes(seed32[4 * i:4 * i + 4], "little") for i in range(8)]
-        self.counter, self.words = 0, []
+    def rotl(v, c):
+        return (v << np.uint32(c)) | (v >> np.uint32(32 - c))
 
-    def _block(self):
-        init = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + self.key + \
-               [self.counter & 0xFFFFFFFF, self.counter >> 32, 0, 0]
-        s = list(init)
+    def quarter(a, b, c, d):
+        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16)
+        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12)
+        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8)
+        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7)
 
-        def rotl(v, c):
-            return ((v << c) & 0xFFFFFFFF) | (v >> (32 - c))
-
-        def quarter(a, b, c, d):
-            s[a] = (s[a] + s[b]) & 0xFFFFFFFF; s[d] = rotl(s[d] ^ s[a], 16)
-            s[c] = (s[c] + s[d]) & 0xFFFFFFFF; s[b] = rotl(s[b] ^ s[c], 12)
-            s[a] = (s[a] + s[b]) & 0xFFFFFFFF; s[d] = rotl(s[d] ^ s[a], 8)
-            s[c] = (s[c] + s[d]) & 0xFFFFFFFF; s[b] = rotl(s[b] ^ s[c], 7)
-
+    with np.errstate(over="ignore"):
         for _ in range(10):
             quarter(0, 4, 8, 12); quarter(1, 5, 9, 13); quarter(2, 6, 10, 14); quarter(3, 7, 11, 15)
             quarter(0, 5, 10, 15); quarter(1, 6, 11, 12); quarter(2, 7, 8, 13); quarter(3, 4, 9, 14)
-        self.counter += 1
-        return [(s[i] + init[i]) & 0xFFFFFFFF for i in range(16)]
-
-    def fr_random(self):
-        v = 0
-        for i in range(16):
-            if not self.words:
-                self.words = self._block()
-            v |= self.words.pop(0) << (32 * i)
-        return v % P
+        s += init
+    blocks = np.ascontiguousarray(s.T).astype("<u4").tobytes()      # element i = 64 consecutive bytes
+    return [int.from_bytes(blocks[64 * i:64 * i + 64], "little") % P for i in range(count)]
 
 
 class _Transcript:
@@ -153,12 +160,58 @@ class _Transcript:
         return int.from_bytes(self.state.copy().digest(), "little") % P
 
 
-# ------------------------------------------------------------------------------------------------ circuit ----
-class ArithmeticCircuit:
-    """arithmetic_circuit.rs: advice l, r, o; fixed sm, sl, sr, so, sc (creation order); instance PI."""
+# -------------------------------------------------------------------------------------------- expressions ----
+# halo2 Expression trees as nested tuples.  Rust operators: a + b -> sum, a - b -> sum(a, neg(b)), a * b -> prod,
+# expr * F -> scaled.
+def _adv(qi, col, rot): return ("advice", qi, col, rot)
+def _fix(qi, col, rot): return ("fixed", qi, col, rot)
+def _sum(a, b): return ("sum", a, b)
+def _sub(a, b): return ("sum", a, ("neg", b))
+def _prod(a, b): return ("prod", a, b)
+def _scaled(a, c): return ("scaled", a, c % P)
+
+
+def _expr_debug(e):
+    t = e[0]
+    if t == "const":
+        return "Constant(0x%064x)" % e[1]
+    if t in ("advice", "fixed", "instance"):
+        return "%s { query_index: %d, column_index: %d, rotation: Rotation(%d) }" % (t.capitalize(), e[1], e[2], e[3])
+    if t == "neg":
+        return "Negated(%s)" % _expr_debug(e[1])
+    if t == "sum":
+        return "Sum(%s, %s)" % (_expr_debug(e[1]), _expr_debug(e[2]))
+    if t == "prod":
+        return "Product(%s, %s)" % (_expr_debug(e[1]), _expr_debug(e[2]))
+    if t == "scaled":
+        return "Scaled(%s, 0x%064x)" % (_expr_debug(e[1]), e[2])
+    raise ValueError(t)
+
+
+# ------------------------------------------------------------------------------------------------ circuits ----
+class Circuit:
+    name = ""
+    num_advice = num_fixed = num_instance = num_selectors = 0
+    degree = 3
+    permutation_columns = []
+    advice_queries = []
+    fixed_queries = []
+    instance_queries = [(0, 0)]
+    constants = []
+    gates = []
+
+    def blinding_factors(self):
+        per_col = {}
+        for col, rot in self.advice_queries:
+            per_col.setdefault(col, set()).add(rot)
+        return max(3, max(len(v) for v in per_col.values())) + 2
+
+
+class ArithmeticCircuit(Circuit):
+    """arithmetic_circuit.rs: advice l, r, o; fixed sm, sl, sr, so, sc (creation order :196-200); instance PI."""
 
     name = "arithmetic"
-    num_advice, num_fixed, num_instance = 3, 5, 1
+    num_advice, num_fixed, num_instance, num_selectors = 3, 5, 1, 0
     degree = 3
     SM, SL, SR, SO, SC = range(5)
     permutation_columns = [("advice", 0), ("advice", 1), ("advice", 2), ("instance", 0)]
@@ -167,18 +220,20 @@ class ArithmeticCircuit:
 
     def __init__(self, x=None, y=None, constant=0):
         self.x, self.y, self.constant = x, y, constant
+        l, r, o = _adv(0, 0, 0), _adv(1, 1, 0), _adv(2, 2, 0)
+        sl, sr, so, sm, sc = _fix(0, 1, 0), _fix(1, 2, 0), _fix(2, 3, 0), _fix(3, 0, 0), _fix(4, 4, 0)
+        # :216  l*sl + r*sr + l*r*sm + (o*so*(-1)) + sc
+        self.gates = [_sum(_sum(_sum(_sum(_prod(l, sl), _prod(r, sr)), _prod(_prod(l, r), sm)),
+                                _scaled(_prod(o, so), P - 1)), sc)]
 
     @classmethod
     def from_json(cls, s):
-        import json
         v = json.loads(s)
         return cls(int(v["x"]), int(v["y"]), int(v["constant"]))
 
-    def without_witnesses(self):
-        return ArithmeticCircuit(None, None, self.constant)
-
-    def blinding_factors(self):
-        return 5
+    def public_inputs(self, s):
+        v = json.loads(s)
+        return [int(v["constant"]), int(v["z"])]            # wasm.rs:93-94
 
     def synthesize_fixed(self, n):
         cols = [[0] * n for _ in range(5)]
@@ -203,16 +258,203 @@ class ArithmeticCircuit:
         return [(a(0, 0), a(1, 0)), (a(0, 1), a(1, 1)), (a(2, 0), a(0, 2)), (a(2, 1), a(1, 2)), (a(2, 2), a(0, 3)),
                 (a(1, 3), (("instance", 0), 0)), (a(2, 3), (("instance", 0), 1))]
 
-    def gates(self, ops, adv, fix, inst):
-        """the 'plonk' gate on extended-domain evaluations: l*sl + r*sr + l*r*sm + (o*so*(-1)) + sc"""
-        l, r, o = adv
-        sm, sl, sr, so, sc = fix
-        t = ops.add(ops.mul(l, sl), ops.mul(r, sr))
-        t = ops.add(t, ops.mul(ops.mul(l, r), sm))
-        t = ops.add(t, ops.scale(ops.mul(o, so), P - 1))
-        return [ops.add(t, sc)]
+
+class _Grain:
+    """Grain LFSR of the Poseidon reference parameter generation (poseidon/primitives/grain.rs:52-137)"""
+
+    def __init__(self, num_bits, t, r_f, r_p):
+        bits = []
+        for width, value in ((2, 1), (4, 0), (12, num_bits), (12, t), (10, r_f), (10, r_p)):
+            bits += [(value >> (width - 1 - i)) & 1 for i in range(width)]
+        self.state = bits + [1] * 30
+        self.num_bits = num_bits
+        for _ in range(160):
+            self._raw()
+
+    def _raw(self):
+        s = self.state
+        b = s[62] ^ s[51] ^ s[38] ^ s[23] ^ s[13] ^ s[0]
+        self.state = s[1:] + [b]
+        return b
+
+    def _bit(self):
+        while True:
+            if self._raw():
+                return self._raw()
+            self._raw()
+
+    def take(self):
+        v = 0
+        for _ in range(self.num_bits):
+            v = (v << 1) | self._bit()
+        return v
 
 
+def _poseidon_constants(t=3, r_f=8, r_p=60):
+    """round constants, Cauchy MDS and its inverse over bn256::Fr (primitives.rs:57-84, mds.rs:5-102)"""
+    g = _Grain(254, t, r_f, r_p)
+    rcs = []
+    for _ in range(r_f + r_p):
+        row = []
+        while len(row) < t:
+            v = g.take()
+            if v < P:
+                row.append(v)
+        rcs.append(row)
+    while True:
+        vals = [g.take() % P for _ in range(2 * t)]
+        if len(set(vals)) == len(vals):
+            break
+    xs, ys = vals[:t], vals[t:]
+    mds = [[pow(xs[i] + ys[j], -1, P) for j in range(t)] for i in range(t)]
+
+    def lag(pts, j, x):
+        acc = 1
+        for m, xm in enumerate(pts):
+            if m != j:
+                acc = acc * (x - xm) % P * pow(pts[j] - xm, -1, P) % P
+        return acc
+
+    nys = [(-y) % P for y in ys]
+    minv = [[(xs[j] - nys[i]) * lag(xs, j, nys[i]) % P * lag(nys, i, xs[j]) % P for j in range(t)] for i in range(t)]
+    return rcs, mds, minv
+
+
+class PoseidonCircuit(Circuit):
+    """poseidon_circuit.rs (:68-123) with the Pow5 chip: WIDTH 3, RATE 2, L 2, R_F 8, R_P 60 (:19-25,129-149).
+    advice state0..2 = 0..2, partial_sbox = 3; fixed rc_a = 0..2, rc_b = 3..5, selector columns 6..8."""
+
+    name = "poseidon"
+    num_advice, num_fixed, num_instance, num_selectors = 4, 9, 1, 3
+    degree = 6
+    permutation_columns = [("instance", 0), ("fixed", 3), ("advice", 0), ("advice", 1), ("advice", 2),
+                           ("fixed", 4), ("fixed", 5)]
+    advice_queries = [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (3, 0), (2, -1), (0, -1), (1, -1)]
+    fixed_queries = [(3, 0), (4, 0), (5, 0), (0, 0), (1, 0), (2, 0), (6, 0), (7, 0), (8, 0)]
+    constants = [3]
+    _CONSTS = None
+
+    def __init__(self, message=None):
+        self.message = None if message is None else [m % P for m in message]
+        if PoseidonCircuit._CONSTS is None:
+            PoseidonCircuit._CONSTS = _poseidon_constants()
+        self.rcs, self.mds, self.minv = PoseidonCircuit._CONSTS
+        mds, minv = self.mds, self.minv
+        s_cur = [_adv(i, i, 0) for i in range(3)]
+        s_next = [_adv(3 + i, i, 1) for i in range(3)]
+        ps = _adv(6, 3, 0)
+        s_prev = [_adv(8, 0, -1), _adv(9, 1, -1), _adv(7, 2, -1)]
+        rc_b = [_fix(i, 3 + i, 0) for i in range(3)]
+        rc_a = [_fix(3 + i, i, 0) for i in range(3)]
+        s_full, s_partial, s_pad = _fix(6, 6, 0), _fix(7, 7, 0), _fix(8, 8, 0)
+
+        def pow5(v):
+            v2 = _prod(v, v)
+            return _prod(_prod(v2, v2), v)
+
+        gates = []
+        for nx in range(3):
+            terms = [_scaled(pow5(_sum(s_cur[i], rc_a[i])), mds[nx][i]) for i in range(3)]
+            gates.append(_prod(s_full, _sub(_sum(_sum(terms[0], terms[1]), terms[2]), s_next[nx])))
+
+        def mid(i):
+            acc = _scaled(ps, mds[i][0])
+            for c in (1, 2):
+                acc = _sum(acc, _scaled(_sum(s_cur[c], rc_a[c]), mds[i][c]))
+            return acc
+
+        def nxt(i):
+            return _sum(_sum(_scaled(s_next[0], minv[i][0]), _scaled(s_next[1], minv[i][1])),
+                        _scaled(s_next[2], minv[i][2]))
+
+        partial = [_sub(pow5(_sum(s_cur[0], rc_a[0])), ps), _sub(pow5(_sum(mid(0), rc_b[0])), nxt(0))]
+        partial += [_sub(_sum(mid(i), rc_b[i]), nxt(i)) for i in (1, 2)]
+        gates += [_prod(s_partial, g) for g in partial]
+        pad = [_sub(_sum(s_prev[i], s_cur[i]), s_next[i]) for i in (0, 1)] + [_sub(s_prev[2], s_next[2])]
+        gates += [_prod(s_pad, g) for g in pad]
+        self.gates = gates
+
+    @classmethod
+    def from_json(cls, s):
+        return cls([int(v) for v in json.loads(s)["x"]])     # poseidon_circuit.rs:37-41, 232-246
+
+    def public_inputs(self, s):
+        out = json.loads(s).get("output")
+        return [int(out, 16)] if out else [self.output()]     # wasm.rs:116 hex_to_fr(output)
+
+    def _permutation_rows(self):
+        rcs, mds = self.rcs, self.mds
+        cap = (2 << 64) % P
+        state = [self.message[0], self.message[1], cap]
+        rows, sbox = [list(state)], {}
+        mix = lambda v: [sum(mds[i][j] * v[j] for j in range(3)) % P for i in range(3)]  # noqa: E731
+        for r in range(4):
+            state = mix([pow((state[i] + rcs[r][i]) % P, 5, P) for i in range(3)])
+            rows.append(list(state))
+        for r in range(30):
+            rnd = 4 + 2 * r
+            r0 = [pow((state[0] + rcs[rnd][0]) % P, 5, P)] + [(state[i] + rcs[rnd][i]) % P for i in (1, 2)]
+            sbox[4 + r] = r0[0]
+            m = mix(r0)
+            state = mix([pow((m[0] + rcs[rnd + 1][0]) % P, 5, P)] + [(m[i] + rcs[rnd + 1][i]) % P for i in (1, 2)])
+            rows.append(list(state))
+        for r in range(4):
+            state = mix([pow((state[i] + rcs[64 + r][i]) % P, 5, P) for i in range(3)])
+            rows.append(list(state))
+        return rows, sbox
+
+    def output(self):
+        return self._permutation_rows()[0][-1][0]
+
+    def synthesize_advice(self, n):
+        adv = [[0] * n for _ in range(4)]
+        m0, m1 = self.message
+        cap = (2 << 64) % P
+        adv[0][0], adv[1][0] = m0, m1
+        adv[2][1] = cap
+        adv[2][2] = cap
+        adv[0][3], adv[1][3] = m0, m1
+        adv[0][4], adv[1][4], adv[2][4] = m0, m1, cap
+        rows, sbox = self._permutation_rows()
+        for off, st in enumerate(rows):
+            for i in range(3):
+                adv[i][5 + off] = st[i]
+        for off, v in sbox.items():
+            adv[3][5 + off] = v
+        return adv
+
+    def synthesize_fixed(self, n):
+        f = [[0] * n for _ in range(9)]
+        rcs = self.rcs
+        f[3][2] = (2 << 64) % P
+        f[8][3] = 1
+        for r in range(4):
+            for i in range(3):
+                f[i][5 + r] = rcs[r][i]
+            f[6][5 + r] = 1
+        for r in range(30):
+            off, rnd = 4 + r, 4 + 2 * r
+            for i in range(3):
+                f[i][5 + off] = rcs[rnd][i]
+                f[3 + i][5 + off] = rcs[rnd + 1][i]
+            f[7][5 + off] = 1
+        for r in range(4):
+            for i in range(3):
+                f[i][5 + 34 + r] = rcs[64 + r][i]
+            f[6][5 + 34 + r] = 1
+        return f
+
+    def copy_constraints(self):
+        a = lambda c, r: (("advice", c), r)  # noqa: E731
+        out = [((("fixed", 3), i), a(i, 1)) for i in range(3)]
+        out += [(a(i, 2), a(i, 1)) for i in range(3)]
+        out += [(a(i, 3), a(i, 0)) for i in range(2)]
+        out += [(a(i, 5), a(i, 4)) for i in range(3)]
+        out.append((a(0, 43), (("instance", 0), 0)))
+        return out
+
+
+# ----------------------------------------------------------------------------------- extended-domain ops ----
 class _ExtOps:
     """expression evaluation on extended-coset evaluation vectors held in HBM"""
 
@@ -235,7 +477,8 @@ class _ExtOps:
 
     def constant(self, c):
         import torch
-        return torch.from_numpy(np.tile(_limbs_of([c]), (self.en, 1)).view(np.int64)).cuda()
+        row = torch.from_numpy(_limbs_of([c]).view(np.int64)).cuda()
+        return row.expand(self.en, 4).contiguous()
 
     def rotate(self, a, rot):
         """evaluations of f(w^rot X) from those of f(X)"""
@@ -244,8 +487,6 @@ class _ExtOps:
 
     def x_column(self):
         """evaluations of the polynomial X on the coset: zeta * extended_omega^i"""
-        import ctypes
-        from . import lib as _lib
         col = self.constant(self.dom.g_coset)
         w = self.dom._m["extended_omega"]
         st = self.dom._L.h2_poly_coset_device(self.dom.curve, ctypes.c_void_p(col.data_ptr()), self.en, 1,
@@ -253,16 +494,41 @@ class _ExtOps:
         _lib.check(st, "h2_poly_coset_device")
         return col
 
+    def evaluate(self, e, cols, cache):
+        """a gate expression on the extended-domain columns cols[kind][column]"""
+        if e in cache:
+            return cache[e]
+        t = e[0]
+        if t == "const":
+            r = self.constant(e[1])
+        elif t in ("advice", "fixed", "instance"):
+            base = cols[t][e[2]]
+            r = base if e[3] == 0 else self.rotate(base, e[3])
+        elif t == "neg":
+            r = self.scale(self.evaluate(e[1], cols, cache), P - 1)
+        elif t == "sum":
+            r = self.add(self.evaluate(e[1], cols, cache), self.evaluate(e[2], cols, cache))
+        elif t == "prod":
+            r = self.mul(self.evaluate(e[1], cols, cache), self.evaluate(e[2], cols, cache))
+        elif t == "scaled":
+            r = self.scale(self.evaluate(e[1], cols, cache), e[2])
+        else:
+            raise ValueError(t)
+        cache[e] = r
+        return r
+
 
 # ------------------------------------------------------------------------------------------------- keygen ----
 def _permutation_mapping(circuit, n):
+    """Assembly::copy of halo2_proofs/src/plonk/permutation/keygen.rs (SURVEY.md App. A.6)"""
     cols = circuit.permutation_columns
     index = {c: i for i, c in enumerate(cols)}
-    mapping = {(c, r): (c, r) for c in range(len(cols)) for r in range(n)}
-    aux = dict(mapping)
-    sizes = {key: 1 for key in mapping}
+    mapping, aux, sizes = {}, {}, {}
     for (lc, lr), (rc, rr) in circuit.copy_constraints():
         left, right = (index[lc], lr), (index[rc], rr)
+        for cell in (left, right):
+            if cell not in mapping:
+                mapping[cell], aux[cell], sizes[cell] = cell, cell, 1
         if aux[left] == aux[right]:
             continue
         big, small = aux[left], aux[right]
@@ -276,41 +542,153 @@ def _permutation_mapping(circuit, n):
             if i == small:
                 break
         mapping[left], mapping[right] = mapping[right], mapping[left]
-    return mapping
+    return mapping            # cells not present map to themselves
+
+
+def vk_debug_string(circuit, k, fixed_commitments, sigma_commitments):
+    """format!("{:?}", vk.pinned()) of halo2_proofs @6b43b6b"""
+    col = lambda kind, i: "Column { index: %d, column_type: %s }" % (i, kind.capitalize())  # noqa: E731
+    pt = lambda q: "Infinity" if q is None else "(0x%064x, 0x%064x)" % q                     # noqa: E731
+    ext_k = k
+    while (1 << ext_k) < (1 << k) * (circuit.degree - 1):
+        ext_k += 1
+    omega = pow(ROOT_OF_UNITY, 1 << (TWO_ADICITY - k), P)
+    s = ('PinnedVerificationKey { base_modulus: "0x%x", scalar_modulus: "0x%x", domain: PinnedEvaluationDomain '
+         '{ k: %d, extended_k: %d, omega: 0x%064x }, ' % (Q, P, k, ext_k, omega))
+    s += ("cs: PinnedConstraintSystem { num_fixed_columns: %d, num_advice_columns: %d, num_instance_columns: %d, "
+          "num_selectors: %d, gates: [%s], " % (circuit.num_fixed, circuit.num_advice, circuit.num_instance,
+                                                circuit.num_selectors, ", ".join(_expr_debug(g) for g in circuit.gates)))
+    s += "advice_queries: [%s], " % ", ".join("(%s, Rotation(%d))" % (col("advice", c), r) for c, r in circuit.advice_queries)
+    s += "instance_queries: [%s], " % ", ".join("(%s, Rotation(%d))" % (col("instance", c), r) for c, r in circuit.instance_queries)
+    s += "fixed_queries: [%s], " % ", ".join("(%s, Rotation(%d))" % (col("fixed", c), r) for c, r in circuit.fixed_queries)
+    s += "permutation: Argument { columns: [%s] }, " % ", ".join(col(kd, i) for kd, i in circuit.permutation_columns)
+    s += "lookups: [], constants: [%s], minimum_degree: None }, " % ", ".join(col("fixed", c) for c in circuit.constants)
+    s += "fixed_commitments: [%s], " % ", ".join(pt(q) for q in fixed_commitments)
+    s += "permutation: VerifyingKey { commitments: [%s] } }" % ", ".join(pt(q) for q in sigma_commitments)
+    return s
 
 
 class ProvingKey:
-    """what keygen_vk + keygen_pk leave behind: fixed and permutation polynomials, their commitments"""
+    """what keygen_vk + keygen_pk leave behind: fixed and permutation polynomials, commitments, vk digest"""
 
-    def __init__(self, params, circuit, transcript_repr):
+    def __init__(self, params, circuit):
         self.params, self.circuit = params, circuit
         self.k, self.n = params.k, params.n
         self.domain = EvaluationDomain(circuit.degree, params.k, "bn254")
         self.omega = self.domain.omega
-        self.transcript_repr = transcript_repr
         n = self.n
         self.fixed_values = circuit.synthesize_fixed(n)
         mapping = _permutation_mapping(circuit, n)
         ncols = len(circuit.permutation_columns)
-        self.sigma_values = [[pow(DELTA, mapping[(j, i)][0], P) * pow(self.omega, mapping[(j, i)][1], P) % P
-                              for i in range(n)] for j in range(ncols)]
+        omega_pows = [1] * n
+        for i in range(1, n):
+            omega_pows[i] = omega_pows[i - 1] * self.omega % P
+        delta_pows = [pow(DELTA, j, P) for j in range(ncols)]
+        self.omega_pows = omega_pows
+        self.sigma_values = []
+        for j in range(ncols):
+            col = [delta_pows[j] * w % P for w in omega_pows]
+            for (cj, row), (tj, trow) in mapping.items():
+                if cj == j:
+                    col[row] = delta_pows[tj] * omega_pows[trow] % P
+            self.sigma_values.append(col)
         cols = self.fixed_values + self.sigma_values
         commits = commit_columns(params, cols, lagrange=True)
         polys = lagrange_to_coeff_columns(self.domain, cols)
         nf = len(self.fixed_values)
         self.fixed_commitments, self.sigma_commitments = commits[:nf], commits[nf:]
         self.fixed_polys, self.sigma_polys = polys[:nf], polys[nf:]
+        s = vk_debug_string(circuit, self.k, self.fixed_commitments, self.sigma_commitments)
+        h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+        h.update(len(s).to_bytes(8, "little"))
+        h.update(s.encode())
+        self.transcript_repr = int.from_bytes(h.digest(), "little") % P
 
 
-def generate_keys(params, circuit, transcript_repr=None):
+def generate_keys(params, circuit):
     """utils.rs:63-70 generate_keys(params, circuit) -> pk (the vk's digest rides along)"""
-    if transcript_repr is None:
-        key = (circuit.name, params.k)
-        if key not in PINNED_TRANSCRIPT_REPR:
-            raise NotImplementedError("transcript_repr of this verifying key is not known: pass it explicitly "
-                                      "(deriving the vk's {:?} string is not implemented, SURVEY.md App. A.6)")
-        transcript_repr = PINNED_TRANSCRIPT_REPR[key]
-    return ProvingKey(params, circuit.without_witnesses(), transcript_repr)
+    return ProvingKey(params, circuit)
+
+
+# ------------------------------------------------------------------------------------------------- setup -----
+_G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+            11559732032986387107991004021392285783925812861821192530917403151452391805634),
+           (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+            4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def _g2_scalar_mul(k, pt):
+    """[k] pt on the BN254 twist y^2 = x^3 + 3/(9+u) over Fq2 = Fq[u]/(u^2+1) (affine, host big integers)"""
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)  # noqa: E731
+    sub = lambda a, b: ((a[0] - b[0]) % Q, (a[1] - b[1]) % Q)                              # noqa: E731
+
+    def inv(a):
+        d = pow(a[0] * a[0] + a[1] * a[1], -1, Q)
+        return (a[0] * d % Q, -a[1] * d % Q)
+
+    def add(p1, p2):
+        if p1 is None:
+            return p2
+        if p2 is None:
+            return p1
+        (x1, y1), (x2, y2) = p1, p2
+        if x1 == x2:
+            if ((y1[0] + y2[0]) % Q, (y1[1] + y2[1]) % Q) == (0, 0):
+                return None
+            lam = mul(mul((3, 0), mul(x1, x1)), inv(((2 * y1[0]) % Q, (2 * y1[1]) % Q)))
+        else:
+            lam = mul(sub(y2, y1), inv(sub(x2, x1)))
+        x3 = sub(sub(mul(lam, lam), x1), x2)
+        return (x3, sub(mul(lam, sub(x1, x3)), y1))
+
+    acc = None
+    while k:
+        if k & 1:
+            acc = add(acc, pt)
+        pt = add(pt, pt)
+        k >>= 1
+    return acc
+
+
+def _g2_bytes(pt):
+    (x0, x1), (y0, y1) = pt
+    return b"".join((v * R_Q % Q).to_bytes(32, "little") for v in (x0, x1, y0, y1))
+
+
+def generate_params(k, rng=None):
+    """utils.rs:59-61 generate_params(k) = ParamsKZG::<Bn256>::new(k): one Fr::random s, g[i] = [s^i]G,
+    g_lagrange[i] = [L_i(s)]G, g2, [s]g2 -- the 2 * 2^k fixed-base multiplications run on the GPU."""
+    import torch
+    from .api import _ensure_init
+    _ensure_init()
+    rng = rng or OsRng()
+    s = rng.fr_random()
+    n = 1 << k
+    L = _lib.load()
+    g_dev = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    s_m = _limbs_of([s])
+    _lib.check(L.h2_srs_generate(0, s_m.ctypes.data, n, ctypes.c_void_p(g_dev.data_ptr()), None), "h2_srs_generate")
+    # L_i(s) = w^i (s^n - 1) / (n (s - w^i))
+    omega = pow(ROOT_OF_UNITY, 1 << (TWO_ADICITY - k), P)
+    w, ws = 1, []
+    for _ in range(n):
+        ws.append(w)
+        w = w * omega % P
+    if pow(s, n, P) == 1:                                    # s on the domain: L_i(s) is an indicator
+        lag = [1 if wi == s else 0 for wi in ws]
+    else:
+        t = (pow(s, n, P) - 1) * pow(n, -1, P) % P
+        inv = _batch_inverse([(s - wi) % P for wi in ws])
+        lag = [wi * t % P * iv % P for wi, iv in zip(ws, inv)]
+    sc_dev = torch.from_numpy(_limbs_of(lag).view(np.int64)).cuda()
+    gl_dev = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    _lib.check(L.h2_fixed_base_mul(0, ctypes.c_void_p(sc_dev.data_ptr()), n, ctypes.c_void_p(gl_dev.data_ptr()), None),
+               "h2_fixed_base_mul")
+    torch.cuda.synchronize()
+    g = g_dev.cpu().numpy().view(np.uint64)
+    gl = gl_dev.cpu().numpy().view(np.uint64)
+    tail = _g2_bytes(_G2_GEN) + _g2_bytes(_g2_scalar_mul(s, _G2_GEN))
+    return ParamsKZG(k, g, gl, tail)
 
 
 # ------------------------------------------------------------------------------------ GPU column helpers ----
@@ -342,7 +720,7 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
     bf, d = circuit.blinding_factors(), circuit.degree
     tr = _Transcript()
     tr.common_scalar(pk.transcript_repr)
-    instance_values = [list(public_input) + [0] * (n - len(public_input))]
+    instance_values = [[v % P for v in public_input] + [0] * (n - len(public_input))]
     for v in public_input:
         tr.common_scalar(v)
 
@@ -363,16 +741,21 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
     pcols = circuit.permutation_columns
     sets = [list(range(s, min(s + d - 2, len(pcols)))) for s in range(0, len(pcols), d - 2)]
     z_values, last_z = [], 1
-    omega_pows = [pow(omega, i, P) for i in range(n)]
+    omega_pows = pk.omega_pows
     for cols in sets:
-        z = [last_z]
+        nums, dens = [1] * (n - 1), [1] * (n - 1)
+        for j in cols:
+            vals = values_of[pcols[j][0]][pcols[j][1]]
+            sig = pk.sigma_values[j]
+            dj_beta = pow(DELTA, j, P) * beta % P
+            for i in range(n - 1):
+                v = vals[i]
+                nums[i] = nums[i] * ((dj_beta * omega_pows[i] + gamma + v) % P) % P
+                dens[i] = dens[i] * ((beta * sig[i] + gamma + v) % P) % P
+        inv = _batch_inverse(dens)
+        z = [last_z] * n
         for i in range(n - 1):
-            num = den = 1
-            for j in cols:
-                v = values_of[pcols[j][0]][pcols[j][1]][i]
-                num = num * (pow(DELTA, j, P) * omega_pows[i] % P * beta + gamma + v) % P
-                den = den * (beta * pk.sigma_values[j][i] + gamma + v) % P
-            z.append(z[i] * num % P * pow(den, -1, P) % P)
+            z[i + 1] = z[i] * nums[i] % P * inv[i] % P
         for row in range(n - bf, n):
             z[row] = rng.fr_random()
         last_z = z[n - bf - 1]
@@ -381,38 +764,43 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
     for pt in commit_columns(params, z_values, lagrange=True):
         tr.write_point(pt)
 
-    # random polynomial of the vanishing argument (one thread chunk)
-    chacha = _ChaCha20Rng(rng.fill(32))
-    random_poly = [chacha.fr_random() for _ in range(n)]
+    # random polynomial of the vanishing argument (one thread chunk: one seed, n sequential draws)
+    random_poly = _chacha20_field_elements(rng.fill(32), n)
     rng.fr_random()
     tr.write_point(commit_columns(params, [random_poly], lagrange=False)[0])
 
     # coefficient forms (one batched inverse NTT on the GPU)
-    lagr = advice_values + instance_values + z_values
-    coeffs = lagrange_to_coeff_columns(dom, lagr)
-    na = len(advice_values)
-    advice_polys, instance_polys, z_polys = coeffs[:na], coeffs[na:na + 1], coeffs[na + 1:]
-    polys_of = {"advice": advice_polys, "fixed": pk.fixed_polys, "instance": instance_polys}
-
-    # quotient on the extended coset
-    y = tr.squeeze_challenge()
-    trace.update(y=y)
-    ops = _ExtOps(dom)
     basis = []
     for rows in ([0], [n - bf - 1], list(range(n - bf, n))):
         v = [0] * n
         for r in rows:
             v[r] = 1
         basis.append(v)
-    l0_c, l_last_c, l_blind_c = lagrange_to_coeff_columns(dom, basis)
-    to_ext = lambda cs: [dom.coeff_to_extended(dom.to_device(_limbs_of(c))) for c in cs]  # noqa: E731
+    coeffs = lagrange_to_coeff_columns(dom, advice_values + instance_values + z_values + basis)
+    na, nz = len(advice_values), len(z_values)
+    advice_polys, instance_polys = coeffs[:na], coeffs[na:na + 1]
+    z_polys = coeffs[na + 1:na + 1 + nz]
+    l0_c, l_last_c, l_blind_c = coeffs[na + 1 + nz:]
+
+    # quotient on the extended coset
+    y = tr.squeeze_challenge()
+    trace.update(y=y)
+    ops = _ExtOps(dom)
+
+    def to_ext(cs):
+        dev = torch.from_numpy(np.stack([_limbs_of(c) for c in cs]).view(np.int64)).cuda()
+        ext = dom.coeff_to_extended(dev)
+        return [ext[j] for j in range(len(cs))]
+
     adv_e, fix_e, inst_e = to_ext(advice_polys), to_ext(pk.fixed_polys), to_ext(instance_polys)
     sig_e, z_e = to_ext(pk.sigma_polys), to_ext(z_polys)
     l0_e, l_last_e, l_blind_e = to_ext([l0_c, l_last_c, l_blind_c])
     one = ops.constant(1)
     l_active_e = ops.sub(ops.sub(one, l_last_e), l_blind_e)
     ext_of = {"advice": adv_e, "fixed": fix_e, "instance": inst_e}
-    terms = list(circuit.gates(ops, adv_e, fix_e, inst_e))
+    cache = {}
+    terms = [ops.evaluate(g, ext_of, cache) for g in circuit.gates]
+    cache.clear()
     terms.append(ops.mul(l0_e, ops.sub(one, z_e[0])))
     terms.append(ops.mul(l_last_e, ops.sub(ops.mul(z_e[-1], z_e[-1]), z_e[-1])))
     for i in range(1, len(sets)):
@@ -432,6 +820,7 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
     h_dev = dom.extended_to_coeff(dom.divide_by_vanishing_poly(numer))
     torch.cuda.synchronize()
     h = _ints_of(h_dev.cpu().numpy().view(np.uint64))
+    del terms, numer, adv_e, fix_e, inst_e, sig_e, z_e, ext_of, h_dev
     h_pieces = [h[i * n:(i + 1) * n] for i in range(d - 1)]
     for pt in commit_columns(params, h_pieces, lagrange=False):
         tr.write_point(pt)
@@ -442,10 +831,11 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
     x = tr.squeeze_challenge()
     trace.update(x=x)
     w_back = pow(omega, -(bf + 1), P)
+    rot_point = lambda rot: x * pow(omega, rot, P) % P  # noqa: E731
     for col, rot in circuit.advice_queries:
-        tr.write_scalar(_horner(advice_polys[col], x * pow(omega, rot, P) % P))
+        tr.write_scalar(_horner(advice_polys[col], rot_point(rot)))
     for col, rot in circuit.fixed_queries:
-        tr.write_scalar(_horner(pk.fixed_polys[col], x * pow(omega, rot, P) % P))
+        tr.write_scalar(_horner(pk.fixed_polys[col], rot_point(rot)))
     tr.write_scalar(_horner(random_poly, x))
     for s in pk.sigma_polys:
         tr.write_scalar(_horner(s, x))
@@ -462,12 +852,12 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
     h_poly = [0] * n
     for piece in reversed(h_pieces):
         h_poly = [(a * xn + b) % P for a, b in zip(h_poly, piece)]
-    queries = [(x * pow(omega, rot, P) % P, advice_polys[col]) for col, rot in circuit.advice_queries]
+    queries = [(rot_point(rot), advice_polys[col]) for col, rot in circuit.advice_queries]
     for zp in z_polys:
         queries += [(x, zp), (x * omega % P, zp)]
     for zp in reversed(z_polys[:-1]):
         queries.append((x * w_back % P, zp))
-    queries += [(x * pow(omega, rot, P) % P, pk.fixed_polys[col]) for col, rot in circuit.fixed_queries]
+    queries += [(rot_point(rot), pk.fixed_polys[col]) for col, rot in circuit.fixed_queries]
     queries += [(x, s) for s in pk.sigma_polys] + [(x, h_poly), (x, random_poly)]
     points = []
     for pt, _ in queries:
@@ -487,12 +877,13 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
 
 
 def wasm_generate_proof(params_bytes, s, circuit_index, rng=None):
-    """wasm.rs:77-122 for circuit 1 (arithmetic): read params, keygen on the empty circuit, prove"""
-    import json
-    if circuit_index != 1:
-        raise NotImplementedError("only the arithmetic circuit (index 1) is restated in this round")
+    """wasm.rs:77-122: read params, keygen on the empty circuit, prove (circuit 1 = arithmetic, 2 = Poseidon)"""
+    if circuit_index == 1:
+        circuit = ArithmeticCircuit.from_json(s)
+    elif circuit_index == 2:
+        circuit = PoseidonCircuit.from_json(s)
+    else:
+        raise NotImplementedError("circuit 0 (Collatz, SHPLONK) is not restated in this round")
     params = ParamsKZG.read(params_bytes)
-    inp = json.loads(s)
-    circuit = ArithmeticCircuit.from_json(s)
     pk = generate_keys(params, circuit)
-    return generate_proof_with_instance(params, pk, circuit, [int(inp["constant"]), int(inp["z"])], rng)
+    return generate_proof_with_instance(params, pk, circuit, circuit.public_inputs(s), rng)

@@ -129,6 +129,10 @@ int h2_msm_plan(uint64_t bases_handle, h2_msm_plan_t* out);
  * wasm.rs:49-55; also how bench.py makes valid synthetic bases without the CPU oracle. */
 int h2_srs_generate(h2_curve_t curve, const uint64_t s[4], size_t n, void* d_out_affine, void* stream);
 
+/* d_out_affine[i] = [k_i] G for n scalars in device memory (Montgomery form): with k_i = L_i(s), the Lagrange
+ * basis at the toxic scalar, this is the g_lagrange vector of ParamsKZG::new(k). */
+int h2_fixed_base_mul(h2_curve_t curve, const void* d_scalars, size_t n, void* d_out_affine, void* stream);
+
 /* ---- kernel timing for bench.py's roofline ---------------------------------------------------
  * While enabled, every MSM launch records HIP events (on the launch stream) around its
  * bucket-accumulate kernel.  h2_profile_read waits for them, returns the sums and resets. */
