@@ -40,9 +40,28 @@ def pscale(a, c):
     return [x * c % P for x in a]
 
 
+def _pmul_fft(a, b):
+    """product through the C oracle's best_fft (used when the schoolbook product would be too slow)"""
+    import numpy as np
+    import oracle_lib as O
+    size = len(a) + len(b) - 1
+    lg = max(1, (size - 1).bit_length())
+    n = 1 << lg
+    w = FR.omega(lg)
+    wl = np.array(FR.limbs(w), dtype=np.uint64)
+    wil = np.array(FR.limbs(pow(w, -1, P)), dtype=np.uint64)
+    fa = O.best_fft(1, np.array([FR.limbs(x) for x in a + [0] * (n - len(a))], dtype=np.uint64), wl, lg, threads=4)
+    fb = O.best_fft(1, np.array([FR.limbs(x) for x in b + [0] * (n - len(b))], dtype=np.uint64), wl, lg, threads=4)
+    fc = O.best_fft(1, O.field_mul_many(1, fa, fb), wil, lg, threads=4)
+    ninv = pow(n, -1, P)
+    return [FR.from_mont(O.limbs_to_int(fc[4 * i:4 * i + 4])) * ninv % P for i in range(size)]
+
+
 def pmul(a, b):
     if not a or not b:
         return []
+    if len(a) * len(b) > (1 << 17):
+        return _pmul_fft(list(a), list(b))
     out = [0] * (len(a) + len(b) - 1)
     for i, x in enumerate(a):
         if x:
@@ -442,6 +461,59 @@ class PoseidonCircuit(Circuit):
         return out
 
 
+class CollatzCircuit(Circuit):
+    """/root/reference/circuits/src/collatz.rs: advice witness, is_odd, is_one; selectors final_entry (0) and
+    selector (1), each compressed into its own fixed column 0 / 1 (SURVEY.md App. A.6); four gates, degree 4;
+    equality on `witness` only and no copy constraints; no instance column.  32 regions laid out by the
+    SimpleFloorPlanner: region i starts at row i(i+3)/2 and uses offsets i, i+1 (:119-134, :180-198)."""
+
+    name = "collatz"
+    num_advice, num_fixed, num_instance, num_selectors = 3, 2, 0, 2
+    degree = 4
+    perm_columns = [("advice", 0)]
+    advice_queries = [(0, 0), (0, 1), (1, 0), (2, 0)]
+    fixed_queries = [(0, 0), (1, 0)]
+    instance_queries = []
+
+    def __init__(self, seq):
+        seq = list(seq)[:32]
+        self.x = [v % P for v in seq] + [1] * (32 - len(seq))          # collatz.rs:256-261
+        x, y, is_odd, is_one = Adv(0, 0, 0), Adv(1, 0, 1), Adv(2, 1, 0), Adv(3, 2, 0)
+        fin, sel = Fix(0, 0, 0), Fix(1, 1, 0)
+        one = Const(1)
+        self.gates = [
+            Prod(sel, Prod(Sub(one, is_odd), Sub(x, Prod(Const(2), y)))),                               # :36-47
+            Prod(Prod(sel, Sub(one, is_one)), Prod(is_odd, Sub(Sum(Prod(Const(3), x), one), y))),        # :49-64
+            Prod(Prod(sel, is_one), Sum(Sub(x, y), Sub(x, one))),                                         # :66-73
+            Prod(fin, Sub(one, x)),                                                                      # :75-79
+        ]
+
+    @staticmethod
+    def _start(i):
+        return i * (i + 3) // 2
+
+    def witness(self, n):
+        adv = [[0] * n for _ in range(3)]
+        for i in range(31):
+            row = self._start(i) + i
+            adv[0][row] = self.x[i]
+            adv[0][row + 1] = self.x[i + 1]
+            adv[1][row] = self.x[i] & 1
+            adv[2][row] = 1 if self.x[i] == 1 else 0
+        adv[0][527 + 31] = self.x[31]
+        return adv
+
+    def fixed_columns(self, n):
+        f = [[0] * n for _ in range(2)]
+        for i in range(31):
+            f[1][self._start(i) + i] = 1       # selector
+        f[0][527 + 31] = 1                     # final_entry
+        return f
+
+    def copies(self):
+        return []
+
+
 def vk_debug_string(circuit, k, fixed_commitments, sigma_commitments):
     """format!("{:?}", vk.pinned()) of halo2_proofs @6b43b6b"""
     def col(kind, i):
@@ -560,7 +632,84 @@ class ProvingKey:
 
 
 # ---------------------------------------------------------------- create_proof (GWC) -------------------------
-def create_proof(pk, backend, instances, rng, trace=None):
+def _interpolate(points, values):
+    """coefficients of the polynomial of degree < len(points) through (points[i], values[i])"""
+    out = []
+    for i, (xi, yi) in enumerate(zip(points, values)):
+        term, den = [1], 1
+        for j, xj in enumerate(points):
+            if j != i:
+                term = pmul(term, [(-xj) % P, 1])
+                den = den * (xi - xj) % P
+        out = padd(out, pscale(term, yi * pow(den, -1, P) % P))
+    return out
+
+
+def shplonk_open(tr, backend, queries, trace):
+    """ProverSHPLONK::create_proof (halo2_proofs/src/poly/kzg/multiopen/shplonk/prover.rs; SURVEY.md App. A.8)."""
+    y = tr.squeeze()
+    v = tr.squeeze()
+    trace.update(shplonk_y=y, v=v)
+    polys = []                                    # (poly, [points]) in first-appearance order, by identity
+    for pt, poly in queries:
+        for entry in polys:
+            if entry[0] is poly:
+                if pt not in entry[1]:
+                    entry[1].append(pt)
+                break
+        else:
+            polys.append((poly, [pt]))
+    groups = []                                   # (sorted point set, [polys]) in first-appearance order
+    for poly, pts in polys:
+        key = sorted(pts)
+        for g in groups:
+            if g[0] == key:
+                g[1].append(poly)
+                break
+        else:
+            groups.append((key, [poly]))
+    T = sorted({pt for key, _ in groups for pt in key})
+    h, vp, per_set = [], 1, []
+    for key, members in groups:
+        n_i, yp, rems = [], 1, []
+        for poly in members:
+            r = _interpolate(key, [peval(poly, pt) for pt in key])
+            rems.append(r)
+            n_i = padd(n_i, pscale(psub(poly, r), yp))
+            yp = yp * y % P
+        q = n_i
+        for pt in key:
+            assert peval(q, pt) == 0
+            q = pdiv_linear(q, pt)
+        h = padd(h, pscale(q, vp))
+        vp = vp * v % P
+        per_set.append((key, members, rems))
+    tr.write_point(backend.commit(h))
+    u = tr.squeeze()
+    trace.update(u=u)
+    zt = 1
+    for pt in T:
+        zt = zt * (u - pt) % P
+    L, vp, z0 = [], 1, None
+    for key, members, rems in per_set:
+        z_i = 1
+        for pt in T:
+            if pt not in key:
+                z_i = z_i * (u - pt) % P
+        if z0 is None:
+            z0 = z_i
+        inner, yp = [], 1
+        for poly, r in zip(members, rems):
+            inner = padd(inner, pscale(psub(poly, [peval(r, u)]), yp))
+            yp = yp * y % P
+        L = padd(L, pscale(inner, vp * z_i % P))
+        vp = vp * v % P
+    L = psub(L, pscale(h, zt))
+    assert peval(L, u) == 0
+    tr.write_point(backend.commit(pscale(pdiv_linear(L, u), pow(z0, -1, P))))
+
+
+def create_proof(pk, backend, instances, rng, trace=None, opening="gwc"):
     """SURVEY.md App. A.4 (phase order, RNG schedule), A.7 (quotient, GWC).  `rng` follows SURVEY App. B.2's
     stream interface (fr_random(field), fill(nbytes)).  Returns the proof bytes."""
     c, n, k, omega = pk.circuit, pk.n, pk.k, pk.omega
@@ -695,9 +844,7 @@ def create_proof(pk, backend, instances, rng, trace=None):
         if i + 1 < len(z_polys):
             tr.write_scalar(peval(zp, x * w_back % P))
 
-    # 8: GWC multiopen
-    v = tr.squeeze()
-    trace.update(v=v)
+    # 8: multiopen
     h_poly = []
     for piece in reversed(h_pieces):
         h_poly = padd(pscale(h_poly, xn), piece)
@@ -711,6 +858,11 @@ def create_proof(pk, backend, instances, rng, trace=None):
     queries += [(x, s) for s in pk.sigma_polys]
     queries.append((x, h_poly))
     queries.append((x, random_poly))
+    if opening == "shplonk":
+        shplonk_open(tr, backend, queries, trace)
+        return tr.proof
+    v = tr.squeeze()
+    trace.update(v=v)
     points = []
     for pt, _ in queries:
         if pt not in points:

@@ -94,3 +94,28 @@ def test_poseidon_k6_proof_matches_reference_record():
     if not os.path.exists(path):
         open(path, "wb").write(proof)
     assert open(path, "rb").read() == proof
+
+
+PROOF_SHA256_COLLATZ_K10 = "8709c25ae65667b14921a4df48907cccc0d7d024ae2f56b2e9e25b6b4d679352"
+COLLATZ_INPUT = [9, 28, 14, 7, 22, 11, 34, 17, 52, 26, 13, 40, 20, 10, 5, 16, 8, 4, 2, 1]
+
+
+def test_collatz_k10_shplonk_proof_matches_reference_record():
+    """circuit 0 of wasm_generate_proof (wasm.rs:83-88, utils.rs:72-93): Collatz sequence of 9, SHPLONK opening,
+    no instance column, k = 10: vk digest (selector compression included) and the 640-byte proof."""
+    from test_oracle_pins import params_bytes_c, PARAMS_SHA256
+    params = params_bytes_c(10)
+    assert hashlib.sha256(params).hexdigest() == PARAMS_SHA256[10]
+    be = H.OracleBackend(params)
+    pk = H.ProvingKey(H.CollatzCircuit(COLLATZ_INPUT), be)
+    assert pk.transcript_repr == H.TRANSCRIPT_REPR[("collatz", 10)]
+    assert pk.sigma_commitments[0] == be._point(be.g[1])        # no copies: sigma_0 = X, committed as [s]G
+    rng = R.SurveyStream(start=8)
+    proof = H.create_proof(pk, be, [], rng, opening="shplonk")
+    assert len(proof) == 640                                     # 8 + 2 points, 10 scalars (SURVEY.md App. A.4)
+    assert hashlib.sha256(proof).hexdigest() == PROOF_SHA256_COLLATZ_K10
+    assert rng.counter == 8 + 31 * 8 + 1
+    path = os.path.join(GOLDEN, "proof_collatz_k10.bin")
+    if not os.path.exists(path):
+        open(path, "wb").write(proof)
+    assert open(path, "rb").read() == proof
