@@ -4,9 +4,11 @@ Mirrors /root/reference/circuits/src/utils.rs and wasm.rs:
     generate_params(k)                                               utils.rs:59-61   ParamsKZG::new (setup)
     generate_keys(params, circuit)                                   utils.rs:63-70   keygen_vk + keygen_pk
     generate_proof_with_instance(params, pk, circuit, public_input)  utils.rs:95-123  create_proof, KZG + GWC, Blake2b
-    wasm_generate_proof(params_bytes, json, circuit_index)           wasm.rs:77-122   circuits 1 (arithmetic), 2 (Poseidon)
-for the arithmetic circuit (arithmetic_circuit.rs) and the Poseidon circuit (poseidon_circuit.rs + Pow5 chip).
-Phase order, transcript, RNG schedule, vk digest and openings follow SURVEY.md App. A.4-A.7.
+    generate_proof(params, pk, circuit)                              utils.rs:72-93   create_proof, KZG + SHPLONK
+    wasm_generate_proof(params_bytes, json, circuit_index)           wasm.rs:77-122   circuits 0, 1, 2
+for the Collatz circuit (collatz.rs), the arithmetic circuit (arithmetic_circuit.rs) and the Poseidon circuit
+(poseidon_circuit.rs + Pow5 chip).  Phase order, transcript, RNG schedule, vk digest and the GWC / SHPLONK
+openings follow SURVEY.md App. A.4-A.8.
 
 What runs where:
   * every commitment  -> ParamsKZG.commit_many -> h2_msm_batch            (GPU, one launch sequence per phase)
@@ -163,6 +165,7 @@ class _Transcript:
 # -------------------------------------------------------------------------------------------- expressions ----
 # halo2 Expression trees as nested tuples.  Rust operators: a + b -> sum, a - b -> sum(a, neg(b)), a * b -> prod,
 # expr * F -> scaled.
+def _const(v): return ("const", v % P)
 def _adv(qi, col, rot): return ("advice", qi, col, rot)
 def _fix(qi, col, rot): return ("fixed", qi, col, rot)
 def _sum(a, b): return ("sum", a, b)
@@ -454,6 +457,59 @@ class PoseidonCircuit(Circuit):
         return out
 
 
+class CollatzCircuit(Circuit):
+    """collatz.rs: advice witness, is_odd, is_one; selectors final_entry (0) / selector (1) compressed into fixed
+    columns 0 / 1; four gates, degree 4; equality on `witness`, no copies, no instance column.  Region i of the
+    SimpleFloorPlanner starts at row i(i+3)/2 and uses offsets i, i+1 (:119-134, :180-198); the last at 527."""
+
+    name = "collatz"
+    num_advice, num_fixed, num_instance, num_selectors = 3, 2, 0, 2
+    degree = 4
+    permutation_columns = [("advice", 0)]
+    advice_queries = [(0, 0), (0, 1), (1, 0), (2, 0)]
+    fixed_queries = [(0, 0), (1, 0)]
+    instance_queries = []
+
+    def __init__(self, seq=None):
+        seq = list(seq or [])[:32]
+        self.x = [v % P for v in seq] + [1] * (32 - len(seq))           # collatz.rs:256-261
+        x, y, is_odd, is_one = _adv(0, 0, 0), _adv(1, 0, 1), _adv(2, 1, 0), _adv(3, 2, 0)
+        fin, sel, one = _fix(0, 0, 0), _fix(1, 1, 0), _const(1)
+        self.gates = [
+            _prod(sel, _prod(_sub(one, is_odd), _sub(x, _prod(_const(2), y)))),
+            _prod(_prod(sel, _sub(one, is_one)), _prod(is_odd, _sub(_sum(_prod(_const(3), x), one), y))),
+            _prod(_prod(sel, is_one), _sum(_sub(x, y), _sub(x, one))),
+            _prod(fin, _sub(one, x)),
+        ]
+
+    @classmethod
+    def from_json(cls, s):
+        return cls([int(v) for v in json.loads(s)["x"]])
+
+    def public_inputs(self, s):
+        return []
+
+    def synthesize_advice(self, n):
+        adv = [[0] * n for _ in range(3)]
+        for i in range(31):
+            row = i * (i + 3) // 2 + i
+            adv[0][row], adv[0][row + 1] = self.x[i], self.x[i + 1]
+            adv[1][row] = self.x[i] & 1
+            adv[2][row] = 1 if self.x[i] == 1 else 0
+        adv[0][527 + 31] = self.x[31]
+        return adv
+
+    def synthesize_fixed(self, n):
+        f = [[0] * n for _ in range(2)]
+        for i in range(31):
+            f[1][i * (i + 3) // 2 + i] = 1
+        f[0][527 + 31] = 1
+        return f
+
+    def copy_constraints(self):
+        return []
+
+
 # ----------------------------------------------------------------------------------- extended-domain ops ----
 class _ExtOps:
     """expression evaluation on extended-coset evaluation vectors held in HBM"""
@@ -713,6 +769,103 @@ def lagrange_to_coeff_columns(domain, columns):
 # ------------------------------------------------------------------------------------------- create_proof ----
 def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, trace=None):
     """utils.rs:95-123: create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC, Challenge255, _, Blake2bWrite, _>"""
+    return _create_proof(params, pk, circuit, public_input, rng, trace, "gwc")
+
+
+def generate_proof(params, pk, circuit, rng=None, trace=None):
+    """utils.rs:72-93: create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK, ...> with instances &[&[]]"""
+    return _create_proof(params, pk, circuit, [], rng, trace, "shplonk")
+
+
+def _interpolate(points, values):
+    """coefficients of the polynomial of degree < len(points) through (points[i], values[i])"""
+    out = [0] * len(points)
+    for i, (xi, yi) in enumerate(zip(points, values)):
+        term, den = [1], 1
+        for j, xj in enumerate(points):
+            if j != i:
+                nt = [0] * (len(term) + 1)
+                for d, c in enumerate(term):
+                    nt[d] = (nt[d] - c * xj) % P
+                    nt[d + 1] = (nt[d + 1] + c) % P
+                term = nt
+                den = den * (xi - xj) % P
+        scale = yi * pow(den, -1, P) % P
+        for d, c in enumerate(term):
+            out[d] = (out[d] + c * scale) % P
+    return out
+
+
+def _shplonk_open(tr, params, n, queries, trace):
+    """ProverSHPLONK::create_proof (SURVEY.md App. A.8): two quotient commitments, both MSMs on the GPU"""
+    y = tr.squeeze_challenge()
+    v = tr.squeeze_challenge()
+    trace.update(shplonk_y=y, v=v)
+    polys = []
+    for pt, poly in queries:
+        for entry in polys:
+            if entry[0] is poly:
+                if pt not in entry[1]:
+                    entry[1].append(pt)
+                break
+        else:
+            polys.append((poly, [pt]))
+    groups = []
+    for poly, pts in polys:
+        key = sorted(pts)
+        for g in groups:
+            if g[0] == key:
+                g[1].append(poly)
+                break
+        else:
+            groups.append((key, [poly]))
+    T = sorted({pt for key, _ in groups for pt in key})
+    h, vp, per_set = [0] * n, 1, []
+    for key, members in groups:
+        acc, yp, rems = [0] * n, 1, []
+        for poly in members:
+            r = _interpolate(key, [_horner(poly, pt) for pt in key])
+            rems.append(r)
+            r_pad = r + [0] * (n - len(r))
+            acc = [(a + yp * (b - c)) % P for a, b, c in zip(acc, poly, r_pad)]
+            yp = yp * y % P
+        q = acc
+        for pt in key:
+            q = _kate_division(q, pt)
+        q = q + [0] * (n - len(q))
+        h = [(a + vp * b) % P for a, b in zip(h, q)]
+        vp = vp * v % P
+        per_set.append((key, members, rems))
+    tr.write_point(commit_columns(params, [h], lagrange=False)[0])
+    u = tr.squeeze_challenge()
+    trace.update(u=u)
+    zt = 1
+    for pt in T:
+        zt = zt * (u - pt) % P
+    L, vp, z0 = [0] * n, 1, None
+    for key, members, rems in per_set:
+        z_i = 1
+        for pt in T:
+            if pt not in key:
+                z_i = z_i * (u - pt) % P
+        if z0 is None:
+            z0 = z_i
+        inner, yp = [0] * n, 1
+        for poly, r in zip(members, rems):
+            ru = _horner(r, u)
+            inner = [(a + yp * b) % P for a, b in zip(inner, poly)]
+            inner[0] = (inner[0] - yp * ru) % P
+            yp = yp * y % P
+        c = vp * z_i % P
+        L = [(a + c * b) % P for a, b in zip(L, inner)]
+        vp = vp * v % P
+    L = [(a - zt * b) % P for a, b in zip(L, h)]
+    z0_inv = pow(z0, -1, P)
+    w = [c * z0_inv % P for c in _kate_division(L, u)]
+    tr.write_point(commit_columns(params, [w], lagrange=False)[0])
+
+
+def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
     import torch
     rng = rng or OsRng()
     trace = trace if trace is not None else {}
@@ -720,9 +873,11 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
     bf, d = circuit.blinding_factors(), circuit.degree
     tr = _Transcript()
     tr.common_scalar(pk.transcript_repr)
-    instance_values = [[v % P for v in public_input] + [0] * (n - len(public_input))]
-    for v in public_input:
-        tr.common_scalar(v)
+    instance_values = []
+    if circuit.num_instance:
+        instance_values = [[v % P for v in public_input] + [0] * (n - len(public_input))]
+        for v in public_input:
+            tr.common_scalar(v)
 
     # advice: synthesize, blind the last bf + 1 rows, commit
     advice_values = circuit.synthesize_advice(n)
@@ -778,9 +933,10 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
         basis.append(v)
     coeffs = lagrange_to_coeff_columns(dom, advice_values + instance_values + z_values + basis)
     na, nz = len(advice_values), len(z_values)
-    advice_polys, instance_polys = coeffs[:na], coeffs[na:na + 1]
-    z_polys = coeffs[na + 1:na + 1 + nz]
-    l0_c, l_last_c, l_blind_c = coeffs[na + 1 + nz:]
+    ni = len(instance_values)
+    advice_polys, instance_polys = coeffs[:na], coeffs[na:na + ni]
+    z_polys = coeffs[na + ni:na + ni + nz]
+    l0_c, l_last_c, l_blind_c = coeffs[na + ni + nz:]
 
     # quotient on the extended coset
     y = tr.squeeze_challenge()
@@ -792,7 +948,8 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
         ext = dom.coeff_to_extended(dev)
         return [ext[j] for j in range(len(cs))]
 
-    adv_e, fix_e, inst_e = to_ext(advice_polys), to_ext(pk.fixed_polys), to_ext(instance_polys)
+    adv_e, fix_e = to_ext(advice_polys), to_ext(pk.fixed_polys)
+    inst_e = to_ext(instance_polys) if instance_polys else []
     sig_e, z_e = to_ext(pk.sigma_polys), to_ext(z_polys)
     l0_e, l_last_e, l_blind_e = to_ext([l0_c, l_last_c, l_blind_c])
     one = ops.constant(1)
@@ -845,9 +1002,7 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
         if i + 1 < len(z_polys):
             tr.write_scalar(_horner(zp, x * w_back % P))
 
-    # GWC multiopen: one quotient commitment per distinct point, batched in one MSM launch sequence
-    v = tr.squeeze_challenge()
-    trace.update(v=v)
+    # multiopen
     xn = pow(x, n, P)
     h_poly = [0] * n
     for piece in reversed(h_pieces):
@@ -859,6 +1014,12 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
         queries.append((x * w_back % P, zp))
     queries += [(rot_point(rot), pk.fixed_polys[col]) for col, rot in circuit.fixed_queries]
     queries += [(x, s) for s in pk.sigma_polys] + [(x, h_poly), (x, random_poly)]
+    if opening == "shplonk":
+        _shplonk_open(tr, params, n, queries, trace)
+        return bytes(tr.bytes)
+    # GWC: one quotient commitment per distinct point, batched in one MSM launch sequence
+    v = tr.squeeze_challenge()
+    trace.update(v=v)
     points = []
     for pt, _ in queries:
         if pt not in points:
@@ -877,13 +1038,12 @@ def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, tr
 
 
 def wasm_generate_proof(params_bytes, s, circuit_index, rng=None):
-    """wasm.rs:77-122: read params, keygen on the empty circuit, prove (circuit 1 = arithmetic, 2 = Poseidon)"""
-    if circuit_index == 1:
-        circuit = ArithmeticCircuit.from_json(s)
-    elif circuit_index == 2:
-        circuit = PoseidonCircuit.from_json(s)
-    else:
-        raise NotImplementedError("circuit 0 (Collatz, SHPLONK) is not restated in this round")
+    """wasm.rs:77-122: read params, keygen on the empty circuit, prove
+    (circuit 0 = Collatz / SHPLONK, 1 = arithmetic / GWC, anything else = Poseidon / GWC, as the reference's match)"""
     params = ParamsKZG.read(params_bytes)
+    if circuit_index == 0:
+        circuit = CollatzCircuit.from_json(s)
+        return generate_proof(params, generate_keys(params, circuit), circuit, rng)
+    circuit = ArithmeticCircuit.from_json(s) if circuit_index == 1 else PoseidonCircuit.from_json(s)
     pk = generate_keys(params, circuit)
     return generate_proof_with_instance(params, pk, circuit, circuit.public_inputs(s), rng)

@@ -98,6 +98,24 @@ def test_gpu_poseidon_k6_proof_is_bit_identical_to_the_reference(h2):
     assert prover.wasm_generate_proof(params_bytes, POSEIDON_INPUT, 2, SurveyRng(8)) == proof
 
 
+def test_gpu_collatz_shplonk_proof_is_bit_identical_to_the_reference(h2):
+    """circuit 0: setup(10) then prove in one process, as the UI does (Circuits.tsx:90) and as recorded"""
+    from halo2_prover_amd import prover
+    rng = SurveyRng(0)
+    params = prover.generate_params(10, rng)
+    assert hashlib.sha256(params.write()).hexdigest() == PARAMS_SHA256[10]
+    seq = [9, 28, 14, 7, 22, 11, 34, 17, 52, 26, 13, 40, 20, 10, 5, 16, 8, 4, 2, 1]
+    circuit = prover.CollatzCircuit(seq)
+    pk = prover.generate_keys(params, circuit)
+    assert pk.transcript_repr == 0x174D961F4BE70218C76F49111B0E742F0EC7583D402762C15220F90E82809AB5
+    proof = prover.generate_proof(params, pk, circuit, rng)
+    assert len(proof) == 640
+    assert hashlib.sha256(proof).hexdigest() == "8709c25ae65667b14921a4df48907cccc0d7d024ae2f56b2e9e25b6b4d679352"
+    assert proof == open(os.path.join(GOLDEN, "proof_collatz_k10.bin"), "rb").read()
+    js = '{"x":%s}' % str(seq).replace(" ", "")
+    assert prover.wasm_generate_proof(params.write(), js, 0, SurveyRng(8)) == proof
+
+
 @pytest.mark.parametrize("k", [4, 6, 10, 11])
 def test_gpu_setup_reproduces_the_reference_params(h2, k):
     """generate_params(k) = ParamsKZG::new(k): g and g_lagrange by GPU fixed-base multiplications"""
