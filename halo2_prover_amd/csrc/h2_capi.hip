@@ -515,6 +515,16 @@ int h2_poly_mul_periodic_device(h2_curve_t curve, void* d_a, size_t n, size_t m,
   return H2_OK;
 }
 
+int h2_poly_inverse_device(h2_curve_t curve, void* d_a, size_t n, void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a) return H2_EINVAL;
+  if (n == 0) return H2_OK;
+  hipError_t e = ops_of((int)curve)->poly_inverse(d_a, n, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "poly_inverse_kernel");
+  return H2_OK;
+}
+
 int h2_poly_pointwise_device(h2_curve_t curve, int op, void* d_a, const void* d_b, size_t n, void* stream_) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_ctx.ready) return H2_ENOTINIT;

@@ -85,6 +85,10 @@ hipError_t poly_mul_periodic(void* d_a, size_t total, const void* d_t, size_t pe
                      (const U128*)d_t, period - 1);
   return hipGetLastError();
 }
+hipError_t poly_inverse(void* d_a, size_t total, hipStream_t s) {
+  hipLaunchKernelGGL(poly_inverse_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a, total);
+  return hipGetLastError();
+}
 hipError_t poly_pointwise(void* d_a, const void* d_b, size_t total, int op, hipStream_t s) {
   hipLaunchKernelGGL(poly_pointwise_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a,
                      (const U128*)d_b, total, op);
@@ -185,7 +189,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers, fixed_base_mul,
                       to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
-                      poly_pointwise, selftest_field, selftest_curve,
+                      poly_pointwise, poly_inverse, selftest_field, selftest_curve,
                       selftest_field_device, selftest_digits};
 
 }  // namespace

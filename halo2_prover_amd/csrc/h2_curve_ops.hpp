@@ -34,6 +34,7 @@ struct CurveOps {
   hipError_t (*poly_powers)(void* d_a, size_t n, size_t m, const uint64_t g[4], hipStream_t s);
   hipError_t (*poly_mul_periodic)(void* d_a, size_t total, const void* d_t, size_t period, hipStream_t s);
   hipError_t (*poly_pointwise)(void* d_a, const void* d_b, size_t total, int op, hipStream_t s);
+  hipError_t (*poly_inverse)(void* d_a, size_t total, hipStream_t s);
   // host self-test hooks (host instantiation of the same templates)
   int (*selftest_field)(int which /* 0 = base field, 1 = scalar field */, int op, const uint64_t* a,
                         const uint64_t* b, uint64_t* out);

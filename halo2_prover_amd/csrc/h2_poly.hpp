@@ -61,6 +61,15 @@ poly_pointwise_kernel(U128* __restrict__ a, const U128* __restrict__ b, size_t t
   }
 }
 
+// a[i] = a[i]^-1 (0 stays 0): the denominators of the permutation grand product
+template <class FP>
+__global__ void __launch_bounds__(256) poly_inverse_kernel(U128* __restrict__ a, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    Fe<FP> x = fe_load<FP>(a + 2 * i);
+    if (!x.is_zero()) fe_store<FP>(a + 2 * i, fe_inv(x));
+  }
+}
+
 inline unsigned poly_grid(size_t total) {
   size_t b = (total + 255) / 256;
   if (b > 256 * 8) b = 256 * 8;  // 8 blocks per CU, grid-stride the rest

@@ -624,34 +624,161 @@ def vk_debug_string(circuit, k, fixed_commitments, sigma_commitments):
     return s
 
 
+class _Dev:
+    """Device-resident columns: torch int64 CUDA tensors (..., n, 4) of Montgomery limbs.  Everything numeric goes
+    through the C ABI (pointwise kernels, NTT, MSM); torch only owns the memory and moves bytes."""
+
+    R2_RAW = None
+    ONE_RAW = None
+
+    def __init__(self, dom, params):
+        import torch
+        self.torch, self.dom, self.params = torch, dom, params
+        self.L, self.curve, self.n = dom._L, dom.curve, dom.n
+        if _Dev.R2_RAW is None:
+            _Dev.R2_RAW = np.frombuffer((R_P * R_P % P).to_bytes(32, "little"), dtype=np.uint64).copy()
+            _Dev.ONE_RAW = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint64).copy()
+
+    def _p(self, t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _scale_raw(self, t, limbs):
+        _lib.check(self.L.h2_poly_scale_device(self.curve, self._p(t), t.numel() // 4, 1, limbs.ctypes.data,
+                                               self.dom._stream()), "h2_poly_scale_device")
+        return t
+
+    # ---- host <-> device -------------------------------------------------------------------------------------
+    def from_ints(self, vals):
+        """canonical ints -> (len, 4) Montgomery column; the multiplication by R runs on the device"""
+        buf = b"".join(v.to_bytes(32, "little") for v in vals)
+        t = self.torch.from_numpy(np.frombuffer(buf, dtype=np.int64).reshape(-1, 4).copy()).cuda()
+        return self._scale_raw(t, _Dev.R2_RAW)          # mont_mul(x, R^2) = x R
+
+    def column(self, vals):
+        """a length-n host column (list of canonical ints); sparse columns only convert their non-zero rows"""
+        rows = [i for i, v in enumerate(vals) if v]
+        if len(rows) * 8 > len(vals):
+            return self.from_ints(vals)
+        t = self.torch.zeros((len(vals), 4), dtype=self.torch.int64, device="cuda")
+        if rows:
+            t[self.torch.tensor(rows, device="cuda")] = self.from_ints([vals[i] for i in rows])
+        return t
+
+    def to_ints(self, t):
+        c = self._scale_raw(t.clone().contiguous(), _Dev.ONE_RAW)   # mont_mul(x R, 1) = x
+        buf = c.cpu().numpy().tobytes()
+        return [int.from_bytes(buf[i:i + 32], "little") for i in range(0, len(buf), 32)]
+
+    def const(self, c, n=None):
+        return self.from_ints([c % P]).expand(n or self.n, 4).contiguous()
+
+    def powers(self, g, n=None):
+        """the column g^i"""
+        t = self.const(1, n)
+        gm = _limbs_of([g])
+        _lib.check(self.L.h2_poly_coset_device(self.curve, self._p(t), t.shape[0], 1, gm.ctypes.data,
+                                               self.dom._stream()), "h2_poly_coset_device")
+        return t
+
+    # ---- arithmetic (new tensors unless named *_) ---------------------------------------------------------------
+    def _pw(self, op, a, b):
+        _lib.check(self.L.h2_poly_pointwise_device(self.curve, op, self._p(a), self._p(b), a.numel() // 4,
+                                                   self.dom._stream()), "h2_poly_pointwise_device")
+        return a
+
+    def add(self, a, b):
+        return self._pw(0, a.clone(), b)
+
+    def sub(self, a, b):
+        return self._pw(1, a.clone(), b)
+
+    def mul(self, a, b):
+        return self._pw(2, a.clone(), b)
+
+    def add_(self, a, b):
+        return self._pw(0, a, b)
+
+    def mul_(self, a, b):
+        return self._pw(2, a, b)
+
+    def scale(self, a, c):
+        cm = _limbs_of([c])
+        t = a.clone()
+        _lib.check(self.L.h2_poly_scale_device(self.curve, self._p(t), t.numel() // 4, 1, cm.ctypes.data,
+                                               self.dom._stream()), "h2_poly_scale_device")
+        return t
+
+    def inverse_(self, t):
+        _lib.check(self.L.h2_poly_inverse_device(self.curve, self._p(t), t.numel() // 4, self.dom._stream()),
+                   "h2_poly_inverse_device")
+        return t
+
+    def evals(self, cols, point):
+        """f_j(point) for the m coefficient-form columns of `cols` (m, n, 4): multiply by the powers of the point
+        and fold the halves together (log2 n pointwise additions over all columns at once)"""
+        m, n = cols.shape[0], cols.shape[1]
+        a = cols.permute(1, 0, 2).contiguous()                              # (n, m, 4): halves are contiguous
+        pw = self.powers(point, n).unsqueeze(1).expand(n, m, 4).contiguous()
+        self.mul_(a, pw)
+        length = n
+        while length > 1:
+            half = length // 2
+            lo, hi = a[:half], a[half:length]
+            _lib.check(self.L.h2_poly_pointwise_device(self.curve, 0, self._p(lo), self._p(hi), half * m,
+                                                       self.dom._stream()), "h2_poly_pointwise_device")
+            length = half
+        return self.to_ints(a[0])
+
+    def commit(self, cols, lagrange):
+        """m device columns (m, n, 4) -> m affine points (canonical ints); the MSM result never leaves the device
+        until it is 96 bytes per column"""
+        cols = cols.contiguous()
+        m, n = cols.shape[0], cols.shape[1]
+        bases = self.params._gl if lagrange else self.params._g
+        out = self.torch.zeros((m, 12), dtype=self.torch.int64, device="cuda")
+        bases.msm_device(cols.data_ptr(), n, m, out.data_ptr(), self.dom._stream().value or 0)
+        self.torch.cuda.synchronize()
+        raw = out.cpu().numpy().tobytes()
+        pts = []
+        for j in range(m):
+            X, Y, Z = (int.from_bytes(raw[96 * j + 32 * i:96 * j + 32 * i + 32], "little") * R_Q_INV % Q for i in range(3))
+            if Z == 0:
+                pts.append(None)
+                continue
+            zi = pow(Z, -1, Q)
+            pts.append((X * zi * zi % Q, Y * zi * zi % Q * zi % Q))
+        return pts
+
+
 class ProvingKey:
-    """what keygen_vk + keygen_pk leave behind: fixed and permutation polynomials, commitments, vk digest"""
+    """what keygen_vk + keygen_pk leave behind, resident in HBM: fixed / permutation columns in Lagrange and
+    coefficient form, their commitments and the vk digest"""
 
     def __init__(self, params, circuit):
+        import torch
         self.params, self.circuit = params, circuit
         self.k, self.n = params.k, params.n
         self.domain = EvaluationDomain(circuit.degree, params.k, "bn254")
         self.omega = self.domain.omega
         n = self.n
-        self.fixed_values = circuit.synthesize_fixed(n)
+        dev = self.dev = _Dev(self.domain, params)
+        self.fixed_values = torch.stack([dev.column(c) for c in circuit.synthesize_fixed(n)])
+        # sigma_j[i] = delta^j w^i except on the cells the copy constraints permute
         mapping = _permutation_mapping(circuit, n)
         ncols = len(circuit.permutation_columns)
-        omega_pows = [1] * n
-        for i in range(1, n):
-            omega_pows[i] = omega_pows[i - 1] * self.omega % P
-        delta_pows = [pow(DELTA, j, P) for j in range(ncols)]
-        self.omega_pows = omega_pows
-        self.sigma_values = []
-        for j in range(ncols):
-            col = [delta_pows[j] * w % P for w in omega_pows]
-            for (cj, row), (tj, trow) in mapping.items():
-                if cj == j:
-                    col[row] = delta_pows[tj] * omega_pows[trow] % P
-            self.sigma_values.append(col)
-        cols = self.fixed_values + self.sigma_values
-        commits = commit_columns(params, cols, lagrange=True)
-        polys = lagrange_to_coeff_columns(self.domain, cols)
-        nf = len(self.fixed_values)
+        self.omega_col = dev.powers(self.omega)
+        sig = torch.stack([dev.scale(self.omega_col, pow(DELTA, j, P)) for j in range(ncols)])
+        moved = [(cell, tgt) for cell, tgt in mapping.items() if cell != tgt]
+        if moved:
+            vals = dev.from_ints([pow(DELTA, tj, P) * pow(self.omega, trow, P) % P for _, (tj, trow) in moved])
+            cj = torch.tensor([c[0] for c, _ in moved], device="cuda")
+            rw = torch.tensor([c[1] for c, _ in moved], device="cuda")
+            sig[cj, rw] = vals
+        self.sigma_values = sig
+        cols = torch.cat([self.fixed_values, self.sigma_values])
+        commits = dev.commit(cols, lagrange=True)
+        polys = self.domain.lagrange_to_coeff(cols.clone())
+        nf = self.fixed_values.shape[0]
         self.fixed_commitments, self.sigma_commitments = commits[:nf], commits[nf:]
         self.fixed_polys, self.sigma_polys = polys[:nf], polys[nf:]
         s = vk_debug_string(circuit, self.k, self.fixed_commitments, self.sigma_commitments)
@@ -747,25 +874,6 @@ def generate_params(k, rng=None):
     return ParamsKZG(k, g, gl, tail)
 
 
-# ------------------------------------------------------------------------------------ GPU column helpers ----
-def commit_columns(params, columns, lagrange):
-    """m columns (lists of canonical ints, length <= n) -> m affine points; one batched MSM launch sequence"""
-    n = params.n
-    cols = [_limbs_of(list(c) + [0] * (n - len(c))) for c in columns]
-    return [_point_of(a) for a in params.commit_many(cols, lagrange=lagrange)]
-
-
-def lagrange_to_coeff_columns(domain, columns):
-    """m Lagrange-basis columns -> coefficient lists, one batched inverse NTT with the n^-1 scaling fused"""
-    import torch
-    m = len(columns)
-    dev = torch.from_numpy(np.stack([_limbs_of(c) for c in columns]).view(np.int64)).cuda()
-    domain.lagrange_to_coeff(dev)
-    torch.cuda.synchronize()
-    host = dev.cpu().numpy().view(np.uint64).reshape(m, domain.n, 4)
-    return [_ints_of(host[j]) for j in range(m)]
-
-
 # ------------------------------------------------------------------------------------------- create_proof ----
 def generate_proof_with_instance(params, pk, circuit, public_input, rng=None, trace=None):
     """utils.rs:95-123: create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC, Challenge255, _, Blake2bWrite, _>"""
@@ -796,133 +904,151 @@ def _interpolate(points, values):
     return out
 
 
-def _shplonk_open(tr, params, n, queries, trace):
-    """ProverSHPLONK::create_proof (SURVEY.md App. A.8): two quotient commitments, both MSMs on the GPU"""
+def _divide_linear_device(dev, col, points):
+    """col / prod (X - p) for a device column known to vanish at the points: the synthetic division is a serial
+    recurrence, so it runs on the host (one column down, one column up)"""
+    q = dev.to_ints(col)
+    for pt in points:
+        q = _kate_division(q, pt)
+    return dev.from_ints(q + [0] * (col.shape[0] - len(q)))
+
+
+def _shplonk_open(tr, dev, n, queries, evals, trace):
+    """ProverSHPLONK::create_proof (SURVEY.md App. A.8).  queries: (point, device column, key); evals[(key, point)]
+    are the already computed evaluations.  Linear combinations run on the device, the two quotient MSMs too."""
     y = tr.squeeze_challenge()
     v = tr.squeeze_challenge()
     trace.update(shplonk_y=y, v=v)
     polys = []
-    for pt, poly in queries:
+    for pt, col, key in queries:
         for entry in polys:
-            if entry[0] is poly:
-                if pt not in entry[1]:
-                    entry[1].append(pt)
+            if entry[0] == key:
+                if pt not in entry[2]:
+                    entry[2].append(pt)
                 break
         else:
-            polys.append((poly, [pt]))
+            polys.append((key, col, [pt]))
     groups = []
-    for poly, pts in polys:
-        key = sorted(pts)
+    for key, col, pts in polys:
+        pset = sorted(pts)
         for g in groups:
-            if g[0] == key:
-                g[1].append(poly)
+            if g[0] == pset:
+                g[1].append((key, col))
                 break
         else:
-            groups.append((key, [poly]))
-    T = sorted({pt for key, _ in groups for pt in key})
-    h, vp, per_set = [0] * n, 1, []
-    for key, members in groups:
-        acc, yp, rems = [0] * n, 1, []
-        for poly in members:
-            r = _interpolate(key, [_horner(poly, pt) for pt in key])
+            groups.append((pset, [(key, col)]))
+    T = sorted({pt for pset, _ in groups for pt in pset})
+    h, vp, per_set = None, 1, []
+    for pset, members in groups:
+        acc, yp, rems = None, 1, []
+        for key, col in members:
+            r = _interpolate(pset, [evals[(key, pt)] for pt in pset])
             rems.append(r)
-            r_pad = r + [0] * (n - len(r))
-            acc = [(a + yp * (b - c)) % P for a, b, c in zip(acc, poly, r_pad)]
+            term = dev.scale(col, yp)
+            acc = term if acc is None else dev.add_(acc, term)
             yp = yp * y % P
-        q = acc
-        for pt in key:
-            q = _kate_division(q, pt)
-        q = q + [0] * (n - len(q))
-        h = [(a + vp * b) % P for a, b in zip(h, q)]
+        # subtract sum_j y^j R_ij (a polynomial of degree < |S_i|)
+        rsum = [0] * len(pset)
+        yp = 1
+        for r in rems:
+            rsum = [(a + yp * b) % P for a, b in zip(rsum, r)]
+            yp = yp * y % P
+        acc[:len(pset)] = dev.sub(acc[:len(pset)].contiguous(), dev.from_ints(rsum))
+        q = _divide_linear_device(dev, acc, pset)
+        term = dev.scale(q, vp)
+        h = term if h is None else dev.add_(h, term)
         vp = vp * v % P
-        per_set.append((key, members, rems))
-    tr.write_point(commit_columns(params, [h], lagrange=False)[0])
+        per_set.append((pset, members, rems))
+    tr.write_point(dev.commit(h.unsqueeze(0), lagrange=False)[0])
     u = tr.squeeze_challenge()
     trace.update(u=u)
     zt = 1
     for pt in T:
         zt = zt * (u - pt) % P
-    L, vp, z0 = [0] * n, 1, None
-    for key, members, rems in per_set:
+    L, vp, z0 = None, 1, None
+    for pset, members, rems in per_set:
         z_i = 1
         for pt in T:
-            if pt not in key:
+            if pt not in pset:
                 z_i = z_i * (u - pt) % P
         if z0 is None:
             z0 = z_i
-        inner, yp = [0] * n, 1
-        for poly, r in zip(members, rems):
-            ru = _horner(r, u)
-            inner = [(a + yp * b) % P for a, b in zip(inner, poly)]
-            inner[0] = (inner[0] - yp * ru) % P
+        inner, yp, const = None, 1, 0
+        for (key, col), r in zip(members, rems):
+            term = dev.scale(col, yp)
+            inner = term if inner is None else dev.add_(inner, term)
+            const = (const + yp * _horner(r, u)) % P
             yp = yp * y % P
-        c = vp * z_i % P
-        L = [(a + c * b) % P for a, b in zip(L, inner)]
+        inner[:1] = dev.sub(inner[:1].contiguous(), dev.from_ints([const]))
+        term = dev.scale(inner, vp * z_i % P)
+        L = term if L is None else dev.add_(L, term)
         vp = vp * v % P
-    L = [(a - zt * b) % P for a, b in zip(L, h)]
-    z0_inv = pow(z0, -1, P)
-    w = [c * z0_inv % P for c in _kate_division(L, u)]
-    tr.write_point(commit_columns(params, [w], lagrange=False)[0])
+    L = dev.sub(L, dev.scale(h, zt))
+    w = dev.scale(_divide_linear_device(dev, L, [u]), pow(z0, -1, P))
+    tr.write_point(dev.commit(w.unsqueeze(0), lagrange=False)[0])
 
 
 def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
     import torch
     rng = rng or OsRng()
     trace = trace if trace is not None else {}
-    n, omega, dom = pk.n, pk.omega, pk.domain
+    n, omega, dom, dev = pk.n, pk.omega, pk.domain, pk.dev
     bf, d = circuit.blinding_factors(), circuit.degree
     tr = _Transcript()
     tr.common_scalar(pk.transcript_repr)
-    instance_values = []
+    instance_cols = []
     if circuit.num_instance:
-        instance_values = [[v % P for v in public_input] + [0] * (n - len(public_input))]
+        instance_cols = [dev.column([v % P for v in public_input] + [0] * (n - len(public_input)))]
         for v in public_input:
             tr.common_scalar(v)
+    instance_values = torch.stack(instance_cols) if instance_cols else torch.zeros((0, n, 4), dtype=torch.int64, device="cuda")
 
     # advice: synthesize, blind the last bf + 1 rows, commit
-    advice_values = circuit.synthesize_advice(n)
-    for col in advice_values:
+    advice_host = circuit.synthesize_advice(n)
+    for col in advice_host:
         for row in range(n - (bf + 1), n):
             col[row] = rng.fr_random()
-    for _ in advice_values:
+    for _ in advice_host:
         rng.fr_random()
-    for pt in commit_columns(params, advice_values, lagrange=True):
+    advice_values = torch.stack([dev.column(c) for c in advice_host])
+    for pt in dev.commit(advice_values, lagrange=True):
         tr.write_point(pt)
     theta, beta, gamma = tr.squeeze_challenge(), tr.squeeze_challenge(), tr.squeeze_challenge()
     trace.update(theta=theta, beta=beta, gamma=gamma)
 
-    # permutation grand products, d - 2 columns per set
+    # permutation grand products, d - 2 columns per set: the per-row ratios on the device, the running product
+    # (a serial recurrence) on the host
     values_of = {"advice": advice_values, "fixed": pk.fixed_values, "instance": instance_values}
     pcols = circuit.permutation_columns
     sets = [list(range(s, min(s + d - 2, len(pcols)))) for s in range(0, len(pcols), d - 2)]
-    z_values, last_z = [], 1
-    omega_pows = pk.omega_pows
+    gamma_col = dev.const(gamma)
+    z_cols, last_z = [], 1
     for cols in sets:
-        nums, dens = [1] * (n - 1), [1] * (n - 1)
+        num = den = None
         for j in cols:
-            vals = values_of[pcols[j][0]][pcols[j][1]]
-            sig = pk.sigma_values[j]
-            dj_beta = pow(DELTA, j, P) * beta % P
-            for i in range(n - 1):
-                v = vals[i]
-                nums[i] = nums[i] * ((dj_beta * omega_pows[i] + gamma + v) % P) % P
-                dens[i] = dens[i] * ((beta * sig[i] + gamma + v) % P) % P
-        inv = _batch_inverse(dens)
+            v = values_of[pcols[j][0]][pcols[j][1]]
+            vg = dev.add(v, gamma_col)
+            tn = dev.add_(dev.scale(pk.omega_col, pow(DELTA, j, P) * beta % P), vg)
+            td = dev.add_(dev.scale(pk.sigma_values[j], beta), vg)
+            num = tn if num is None else dev.mul_(num, tn)
+            den = td if den is None else dev.mul_(den, td)
+        ratio = dev.to_ints(dev.mul_(num, dev.inverse_(den)))
         z = [last_z] * n
-        for i in range(n - 1):
-            z[i + 1] = z[i] * nums[i] % P * inv[i] % P
+        for i in range(n - bf - 1):
+            z[i + 1] = z[i] * ratio[i] % P
         for row in range(n - bf, n):
             z[row] = rng.fr_random()
         last_z = z[n - bf - 1]
         rng.fr_random()
-        z_values.append(z)
-    for pt in commit_columns(params, z_values, lagrange=True):
+        z_cols.append(dev.from_ints(z))
+    z_values = torch.stack(z_cols)
+    for pt in dev.commit(z_values, lagrange=True):
         tr.write_point(pt)
 
     # random polynomial of the vanishing argument (one thread chunk: one seed, n sequential draws)
-    random_poly = _chacha20_field_elements(rng.fill(32), n)
+    random_poly = dev.from_ints(_chacha20_field_elements(rng.fill(32), n))
     rng.fr_random()
-    tr.write_point(commit_columns(params, [random_poly], lagrange=False)[0])
+    tr.write_point(dev.commit(random_poly.unsqueeze(0), lagrange=False)[0])
 
     # coefficient forms (one batched inverse NTT on the GPU)
     basis = []
@@ -930,28 +1056,20 @@ def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
         v = [0] * n
         for r in rows:
             v[r] = 1
-        basis.append(v)
-    coeffs = lagrange_to_coeff_columns(dom, advice_values + instance_values + z_values + basis)
-    na, nz = len(advice_values), len(z_values)
-    ni = len(instance_values)
+        basis.append(dev.column(v))
+    na, ni, nz = advice_values.shape[0], instance_values.shape[0], z_values.shape[0]
+    coeffs = dom.lagrange_to_coeff(torch.cat([advice_values, instance_values, z_values, torch.stack(basis)]))
     advice_polys, instance_polys = coeffs[:na], coeffs[na:na + ni]
-    z_polys = coeffs[na + ni:na + ni + nz]
-    l0_c, l_last_c, l_blind_c = coeffs[na + ni + nz:]
+    z_polys, basis_polys = coeffs[na + ni:na + ni + nz], coeffs[na + ni + nz:]
 
     # quotient on the extended coset
     y = tr.squeeze_challenge()
     trace.update(y=y)
     ops = _ExtOps(dom)
-
-    def to_ext(cs):
-        dev = torch.from_numpy(np.stack([_limbs_of(c) for c in cs]).view(np.int64)).cuda()
-        ext = dom.coeff_to_extended(dev)
-        return [ext[j] for j in range(len(cs))]
-
-    adv_e, fix_e = to_ext(advice_polys), to_ext(pk.fixed_polys)
-    inst_e = to_ext(instance_polys) if instance_polys else []
-    sig_e, z_e = to_ext(pk.sigma_polys), to_ext(z_polys)
-    l0_e, l_last_e, l_blind_e = to_ext([l0_c, l_last_c, l_blind_c])
+    adv_e, fix_e = dom.coeff_to_extended(advice_polys), dom.coeff_to_extended(pk.fixed_polys)
+    inst_e = dom.coeff_to_extended(instance_polys) if ni else []
+    sig_e, z_e = dom.coeff_to_extended(pk.sigma_polys), dom.coeff_to_extended(z_polys)
+    l0_e, l_last_e, l_blind_e = dom.coeff_to_extended(basis_polys)
     one = ops.constant(1)
     l_active_e = ops.sub(ops.sub(one, l_last_e), l_blind_e)
     ext_of = {"advice": adv_e, "fixed": fix_e, "instance": inst_e}
@@ -963,76 +1081,87 @@ def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
     for i in range(1, len(sets)):
         terms.append(ops.mul(l0_e, ops.sub(z_e[i], ops.rotate(z_e[i - 1], -(bf + 1)))))
     x_col = ops.x_column()
-    gamma_col = ops.constant(gamma)
+    gamma_ext = ops.constant(gamma)
     for i, cols in enumerate(sets):
         left, right = ops.rotate(z_e[i], 1), z_e[i]
         for j in cols:
             v = ext_of[pcols[j][0]][pcols[j][1]]
-            left = ops.mul(left, ops.add(ops.add(v, ops.scale(sig_e[j], beta)), gamma_col))
-            right = ops.mul(right, ops.add(ops.add(v, ops.scale(x_col, pow(DELTA, j, P) * beta % P)), gamma_col))
+            left = ops.mul(left, ops.add(ops.add(v, ops.scale(sig_e[j], beta)), gamma_ext))
+            right = ops.mul(right, ops.add(ops.add(v, ops.scale(x_col, pow(DELTA, j, P) * beta % P)), gamma_ext))
         terms.append(ops.mul(l_active_e, ops.sub(left, right)))
     numer = terms[0]
     for t in terms[1:]:
         numer = ops.add(ops.scale(numer, y), t)
-    h_dev = dom.extended_to_coeff(dom.divide_by_vanishing_poly(numer))
-    torch.cuda.synchronize()
-    h = _ints_of(h_dev.cpu().numpy().view(np.uint64))
-    del terms, numer, adv_e, fix_e, inst_e, sig_e, z_e, ext_of, h_dev
-    h_pieces = [h[i * n:(i + 1) * n] for i in range(d - 1)]
-    for pt in commit_columns(params, h_pieces, lagrange=False):
+    h_pieces = dom.extended_to_coeff(dom.divide_by_vanishing_poly(numer)).view(d - 1, n, 4)
+    del terms, numer, adv_e, fix_e, inst_e, sig_e, z_e, ext_of
+    for pt in dev.commit(h_pieces, lagrange=False):
         tr.write_point(pt)
-    for _ in h_pieces:
+    for _ in range(d - 1):
         rng.fr_random()
 
-    # evaluations at x
+    # evaluations at x: every (polynomial, point) pair once, batched per point on the device
     x = tr.squeeze_challenge()
     trace.update(x=x)
     w_back = pow(omega, -(bf + 1), P)
     rot_point = lambda rot: x * pow(omega, rot, P) % P  # noqa: E731
+    wanted = []                                            # (key, device column, point) in transcript order
     for col, rot in circuit.advice_queries:
-        tr.write_scalar(_horner(advice_polys[col], rot_point(rot)))
+        wanted.append((("advice", col), advice_polys[col], rot_point(rot)))
     for col, rot in circuit.fixed_queries:
-        tr.write_scalar(_horner(pk.fixed_polys[col], rot_point(rot)))
-    tr.write_scalar(_horner(random_poly, x))
-    for s in pk.sigma_polys:
-        tr.write_scalar(_horner(s, x))
-    for i, zp in enumerate(z_polys):
-        tr.write_scalar(_horner(zp, x))
-        tr.write_scalar(_horner(zp, x * omega % P))
-        if i + 1 < len(z_polys):
-            tr.write_scalar(_horner(zp, x * w_back % P))
+        wanted.append((("fixed", col), pk.fixed_polys[col], rot_point(rot)))
+    wanted.append((("random", 0), random_poly, x))
+    for j in range(pk.sigma_polys.shape[0]):
+        wanted.append((("sigma", j), pk.sigma_polys[j], x))
+    for i in range(nz):
+        wanted.append((("z", i), z_polys[i], x))
+        wanted.append((("z", i), z_polys[i], x * omega % P))
+        if i + 1 < nz:
+            wanted.append((("z", i), z_polys[i], x * w_back % P))
+    evals = {}
+    by_point = {}
+    for key, col, pt in wanted:
+        by_point.setdefault(pt, []).append((key, col))
+    for pt, items in by_point.items():
+        vals = dev.evals(torch.stack([c for _, c in items]), pt)
+        for (key, _), val in zip(items, vals):
+            evals[(key, pt)] = val
+    for key, _, pt in wanted:
+        tr.write_scalar(evals[(key, pt)])
 
     # multiopen
     xn = pow(x, n, P)
-    h_poly = [0] * n
-    for piece in reversed(h_pieces):
-        h_poly = [(a * xn + b) % P for a, b in zip(h_poly, piece)]
-    queries = [(rot_point(rot), advice_polys[col]) for col, rot in circuit.advice_queries]
-    for zp in z_polys:
-        queries += [(x, zp), (x * omega % P, zp)]
-    for zp in reversed(z_polys[:-1]):
-        queries.append((x * w_back % P, zp))
-    queries += [(rot_point(rot), pk.fixed_polys[col]) for col, rot in circuit.fixed_queries]
-    queries += [(x, s) for s in pk.sigma_polys] + [(x, h_poly), (x, random_poly)]
+    h_poly = h_pieces[d - 2].clone()
+    for i in range(d - 3, -1, -1):
+        h_poly = dev.add_(dev.scale(h_poly, xn), h_pieces[i])
+    queries = [(rot_point(rot), advice_polys[col], ("advice", col)) for col, rot in circuit.advice_queries]
+    for i in range(nz):
+        queries += [(x, z_polys[i], ("z", i)), (x * omega % P, z_polys[i], ("z", i))]
+    for i in range(nz - 2, -1, -1):
+        queries.append((x * w_back % P, z_polys[i], ("z", i)))
+    queries += [(rot_point(rot), pk.fixed_polys[col], ("fixed", col)) for col, rot in circuit.fixed_queries]
+    queries += [(x, pk.sigma_polys[j], ("sigma", j)) for j in range(pk.sigma_polys.shape[0])]
+    queries += [(x, h_poly, ("h", 0)), (x, random_poly, ("random", 0))]
     if opening == "shplonk":
-        _shplonk_open(tr, params, n, queries, trace)
+        evals[(("h", 0), x)] = dev.evals(h_poly.unsqueeze(0), x)[0]
+        _shplonk_open(tr, dev, n, queries, evals, trace)
         return bytes(tr.bytes)
-    # GWC: one quotient commitment per distinct point, batched in one MSM launch sequence
+    # GWC: one witness polynomial per distinct point; the v-power combinations on the device
     v = tr.squeeze_challenge()
     trace.update(v=v)
     points = []
-    for pt, _ in queries:
+    for pt, _, _ in queries:
         if pt not in points:
             points.append(pt)
     witnesses = []
     for pt in points:
-        acc, vp = [0] * n, 1
-        for qpt, poly in queries:
+        acc, vp = None, 1
+        for qpt, col, _ in queries:
             if qpt == pt:
-                acc = [(a + vp * b) % P for a, b in zip(acc, poly)]
+                term = dev.scale(col, vp)
+                acc = term if acc is None else dev.add_(acc, term)
                 vp = vp * v % P
-        witnesses.append(_kate_division(acc, pt))
-    for pt in commit_columns(params, witnesses, lagrange=False):
+        witnesses.append(_divide_linear_device(dev, acc, [pt]))
+    for pt in dev.commit(torch.stack(witnesses), lagrange=False):
         tr.write_point(pt)
     return bytes(tr.bytes)
 

@@ -109,6 +109,8 @@ int h2_poly_coset_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const 
 /* a[i] *= t[i mod period], period a power of two: divide_by_vanishing_poly with t = t_evaluations */
 int h2_poly_mul_periodic_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const void* d_t, size_t period,
                                 void* stream);
+/* a[i] = 1 / a[i] over n elements (zero stays zero): the permutation argument's denominators */
+int h2_poly_inverse_device(h2_curve_t curve, void* d_a, size_t n, void* stream);
 /* a[i] = a[i] op b[i] over n elements; op 0 = add, 1 = sub, 2 = mul */
 int h2_poly_pointwise_device(h2_curve_t curve, int op, void* d_a, const void* d_b, size_t n, void* stream);
 
