@@ -717,7 +717,8 @@ class _Dev:
         """f_j(point) for the m coefficient-form columns of `cols` (m, n, 4): multiply by the powers of the point
         and fold the halves together (log2 n pointwise additions over all columns at once)"""
         m, n = cols.shape[0], cols.shape[1]
-        a = cols.permute(1, 0, 2).contiguous()                              # (n, m, 4): halves are contiguous
+        # (n, m, 4) so that halves are contiguous; always a fresh copy: the fold below works in place
+        a = cols.permute(1, 0, 2).clone(memory_format=self.torch.contiguous_format)
         pw = self.powers(point, n).unsqueeze(1).expand(n, m, 4).contiguous()
         self.mul_(a, pw)
         length = n
