@@ -331,8 +331,8 @@ def proof_generation(k):
             "keygen_ms": round((t2 - t1) * 1e3, 1), "create_proof_ms": round((t3 - t2) * 1e3, 1),
             "proof_gen_ms": round((t3 - t1) * 1e3, 1), "proof_bytes": len(proof), "proof_sha256": digest,
             "bit_identical_to_reference": (digest == REFERENCE_PROOF_SHA256[k]) if k in REFERENCE_PROOF_SHA256 else None,
-            "note": "proof_gen_ms = keygen + create_proof as wasm_generate_proof does; host-side Python (witness, "
-                    "transcript, Horner, GWC divisions, limb conversions) is included and dominates"}
+            "note": "proof_gen_ms = keygen + create_proof as wasm_generate_proof does (wall clock, host side "
+                    "included: witness synthesis, transcript, grand-product recurrence, GWC divisions)"}
 
 
 def cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R):

@@ -16,9 +16,12 @@ What runs where:
   * the quotient h(X): coset NTTs of every column, the gate / permutation expressions with the pointwise kernels,
     divide_by_vanishing_poly, inverse coset NTT                          (GPU, EvaluationDomain)
   * setup: g = [s^i]G and g_lagrange = [L_i(s)]G                         (GPU, h2_srs_generate / h2_fixed_base_mul)
-  * transcript hashing, Horner evaluations at x, the GWC synthetic divisions, witness synthesis, the permutation
-    union-find and grand products                                        (host Python, big integers)
-There is no CPU fallback for the GPU parts.  Scalars cross the boundary as 4 x u64 Montgomery limbs.
+  * evaluations at x (powers-multiply + folding adds), the v-power combinations of the openings and the
+    grand-product ratios (per-element inverse kernel)                    (GPU, pointwise kernels on resident columns)
+  * transcript hashing, witness synthesis, the permutation union-find, the grand-product running product and
+    the synthetic divisions of the openings                              (host Python, big integers)
+There is no CPU fallback for the GPU parts.  Columns stay resident in HBM as 4 x u64 Montgomery limbs; the
+conversion from / to canonical integers runs on the device.
 """
 import ctypes
 import hashlib
@@ -47,19 +50,6 @@ def _limbs_of(vals):
     """canonical ints -> (n, 4) uint64 Montgomery limbs"""
     buf = b"".join((v % P * R_P % P).to_bytes(32, "little") for v in vals)
     return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
-
-
-def _ints_of(limbs):
-    buf = np.ascontiguousarray(limbs, dtype=np.uint64).tobytes()
-    return [int.from_bytes(buf[i:i + 32], "little") * R_P_INV % P for i in range(0, len(buf), 32)]
-
-
-def _point_of(aff):
-    """(8,) Montgomery limbs of an affine G1 point -> canonical (x, y) or None for the identity"""
-    b = np.ascontiguousarray(aff, dtype=np.uint64).tobytes()
-    x = int.from_bytes(b[:32], "little") * R_Q_INV % Q
-    y = int.from_bytes(b[32:], "little") * R_Q_INV % Q
-    return None if x == 0 and y == 0 else (x, y)
 
 
 def _horner(coeffs, x):
