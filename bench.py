@@ -117,7 +117,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ     # under torch.distributed.run the collective path is exercised
+    if use_dist:                                       # even with one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import halo2_prover_amd as h2
@@ -177,7 +180,7 @@ def main():
     ntt_bufs = []
     for j, (lg, m, inv) in enumerate(ntts):
         ntt_bufs.append((to_dev(splitmix_columns(seed | (2 + j), m << lg, p)), lg, m, omega(lg, inv)))
-    gathered = torch.zeros((world * max(n_msm, 1), 12), dtype=torch.int64, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * max(n_msm, 1), 12), dtype=torch.int64, device=dev) if use_dist else None
 
     def msm_phase():
         off = 0
@@ -192,11 +195,11 @@ def main():
     def step():
         msm_phase()
         ntt_phase()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, msm_out)   # the one collective: the commitment vector
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,10 +215,12 @@ def main():
     prof = h2lib.Profile()
     h2lib.check(L.h2_profile_read(ctypes.byref(prof)), "h2_profile_read")
     L.h2_profile_enable(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank's slice of the gathered commitment vector must be that rank's own result
+        assert torch.equal(gathered[rank * max(n_msm, 1):(rank + 1) * max(n_msm, 1)], msm_out)
 
     # per-phase timing (outside the timed region; torch events see this stream because the library was
     # handed torch's current stream)
@@ -275,7 +280,7 @@ def main():
             "field_ops_per_step": ops_step,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
