@@ -22,7 +22,8 @@
 //    consecutive sorted entries (mixed XYZZ additions, 8M + 2S) whatever bucket they belong
 //    to, writes complete runs straight to the bucket and its cut-off head / tail runs to
 //    partial slots; a fix-up kernel sums each bucket's pieces with G lanes and a DPP shuffle
-//    tree, multiplies by the bucket weight (b+1) and a two-level tree sums the buckets.
+//    tree (buckets cut into hundreds of pieces -- degenerate columns -- first go through a
+//    wave-per-128-pieces reduction), then the bucket weights (b+1) and a two-level tree sum.
 #pragma once
 #include "h2_curve.hpp"
 
@@ -31,6 +32,9 @@ namespace h2 {
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 constexpr uint32_t MSM_TREE_SEG = 128;    // points summed by one wave of the first tree level
 constexpr uint32_t MSM_MAX_WINDOWS = 48;
+constexpr uint32_t MSM_HOT_SPAN = 256;    // keys cut into more pieces than this take the hierarchical path
+constexpr uint32_t MSM_HOT_SEG = 128;     // pieces summed by one wave of msm_hot_reduce_kernel
+constexpr uint32_t MSM_NOT_HOT = 0xFFFFFFFFu;
 constexpr uint32_t MSM_MAX_C = 16;        // B*4 bytes of LDS histogram must fit one CU: 2^15 * 4 = 128 KiB
 
 struct MsmGeom {
@@ -303,13 +307,71 @@ __device__ __forceinline__ Xyzz<CV> xyzz_shfl_down(const Xyzz<CV>& p, uint32_t d
   return r;
 }
 
+// piece p of a key whose list starts at entry s and spans chunks j0..: p = 0 is chunk j0's tail (or head when the
+// list starts exactly at the chunk), p >= 1 is the head of chunk j0 + p
+template <class CV>
+__device__ __forceinline__ Xyzz<CV> msm_piece(const U128* __restrict__ head, const U128* __restrict__ tail, uint32_t s,
+                                             uint32_t j0, uint32_t T, uint32_t p) {
+  const uint32_t j = j0 + p;
+  const U128* src = (p == 0 && s != j0 * T) ? tail + 8 * (size_t)j : head + 8 * (size_t)j;
+  return xyzz_load<CV>(src);
+}
+
+// Degenerate columns (a permutation grand product that is 1 on almost every row, an all-ones selector) put tens of
+// thousands of entries into one bucket.  The chunk kernel does not care -- every thread still adds T entries -- but
+// the bucket then has thousands of pieces.  One thread per key: keys with more than MSM_HOT_SPAN pieces reserve
+// ceil(span / MSM_HOT_SEG) slots and emit one task per slot.
+static __global__ void __launch_bounds__(256)
+msm_hot_tasks_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t* __restrict__ hot_slot,
+                     uint32_t* __restrict__ tasks /* 2 words each: key, segment */, uint32_t* task_count,
+                     uint32_t max_tasks) {
+  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= K) return;
+  const uint32_t s = offsets[key], e = offsets[key + 1];
+  uint32_t slot = MSM_NOT_HOT;
+  if (e > s) {
+    const uint32_t span = (e - 1) / T - s / T + 1;
+    if (span > MSM_HOT_SPAN) {
+      const uint32_t nseg = (span + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
+      const uint32_t first = atomicAdd(task_count, nseg);
+      if (first + nseg <= max_tasks) {       // cannot fail by construction (see msm_workspace); stay in bounds anyway
+        slot = first;
+        for (uint32_t q = 0; q < nseg; q++) {
+          tasks[2 * (first + q)] = (uint32_t)key;
+          tasks[2 * (first + q) + 1] = q;
+        }
+      }
+    }
+  }
+  hot_slot[key] = slot;
+}
+
+// one wave per task: sum MSM_HOT_SEG consecutive pieces of a hot key (2 per lane, then a 6-level shuffle tree)
+template <class CV>
+__global__ void __launch_bounds__(64)
+msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const uint32_t* __restrict__ hot_slot,
+                      const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t max_tasks,
+                      const U128* __restrict__ head, const U128* __restrict__ tail, U128* __restrict__ hot_part) {
+  const uint32_t ntask = min(*task_count, max_tasks);
+  for (uint32_t t = blockIdx.x; t < ntask; t += gridDim.x) {
+    const uint32_t key = tasks[2 * t], q = tasks[2 * t + 1];
+    const uint32_t s = offsets[key], e = offsets[key + 1];
+    const uint32_t j0 = s / T, span = (e - 1) / T - j0 + 1;
+    const uint32_t lo = q * MSM_HOT_SEG, hi = min(span, lo + MSM_HOT_SEG);
+    Xyzz<CV> a = Xyzz<CV>::identity();
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += 64) a = xyzz_add(a, msm_piece<CV>(head, tail, s, j0, T, p));
+    for (uint32_t d = 32; d > 0; d >>= 1) a = xyzz_add(a, xyzz_shfl_down(a, d));
+    if (threadIdx.x == 0) xyzz_store<CV>(hot_part + 8 * (size_t)(hot_slot[key] + q), a);
+  }
+}
+
 // Fix-up: G lanes (G = 2^log_g <= 64) per key sum the key's pieces when its list was cut across chunks;
 // lane 0 writes xsum[key] (the bucket's point sum).
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g,
                  const U128* __restrict__ bucket_sum, const U128* __restrict__ head, const U128* __restrict__ tail,
-                 U128* __restrict__ xsum) {
+                 const uint32_t* __restrict__ hot_slot, const U128* __restrict__ hot_part, U128* __restrict__ xsum) {
   const uint32_t G = 1u << log_g;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> log_g;
@@ -323,11 +385,12 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
       const uint32_t j0 = s / T, j1 = (e - 1) / T;
       if (j0 == j1) {
         if (lane == 0) x = xyzz_load<CV>(bucket_sum + 8 * key);
+      } else if (hot_slot[key] != MSM_NOT_HOT) {
+        const uint32_t nseg = (j1 - j0 + 1 + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
+        const U128* part = hot_part + 8 * (size_t)hot_slot[key];
+        for (uint32_t q = lane; q < nseg; q += G) x = xyzz_add(x, xyzz_load<CV>(part + 8 * (size_t)q));
       } else {
-        for (uint32_t j = j0 + lane; j <= j1; j += G) {
-          const U128* src = (j == j0 && s != j0 * T) ? tail + 8 * (size_t)j : head + 8 * (size_t)j;
-          x = xyzz_add(x, xyzz_load<CV>(src));
-        }
+        for (uint32_t p = lane; p <= j1 - j0; p += G) x = xyzz_add(x, msm_piece<CV>(head, tail, s, j0, T, p));
       }
     }
   }
@@ -465,7 +528,8 @@ struct MsmWorkspace {
   uint32_t tile;        // scalars per block in the digits / scatter kernels
   uint32_t lvl1;        // partials per column after the first tree level
   size_t off_digits, off_counts, off_offsets, off_cursor, off_blocksums, off_ref, off_key, off_misc, off_bsum,
-      off_head, off_tail, off_xsum, off_weighted, off_tree1, off_tree2, total;
+      off_head, off_tail, off_xsum, off_weighted, off_tree1, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
+  uint32_t max_tasks;
 };
 inline size_t h2_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
@@ -515,6 +579,12 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_weighted = o; o = h2_align256(o + ws.K * 128);
   ws.off_tree1 = o; o = h2_align256(o + m * ws.lvl1 * 128);
   ws.off_tree2 = o; o = h2_align256(o + m * 128);
+  // hot keys: a key with span > MSM_HOT_SPAN emits ceil(span / SEG) <= span / SEG + 1 <= span / SEG + span / SPAN
+  // tasks, and the spans of all keys add up to at most nchunks + K_hot <= nchunks * (1 + 1 / SPAN)
+  ws.max_tasks = (uint32_t)(ws.nchunks / MSM_HOT_SEG + 2 * (ws.nchunks / MSM_HOT_SPAN) + 16);
+  ws.off_hot_slot = o; o = h2_align256(o + ws.K * 4);
+  ws.off_hot_tasks = o; o = h2_align256(o + (size_t)ws.max_tasks * 8);
+  ws.off_hot_part = o; o = h2_align256(o + (size_t)ws.max_tasks * 128);
   ws.total = o;
   return ws;
 }
@@ -541,9 +611,13 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   U128* weighted = (U128*)(ws_base + ws.off_weighted);
   U128* tree1 = (U128*)(ws_base + ws.off_tree1);
   U128* tree2 = (U128*)(ws_base + ws.off_tree2);
+  uint32_t* hot_slot = (uint32_t*)(ws_base + ws.off_hot_slot);
+  uint32_t* hot_tasks = (uint32_t*)(ws_base + ws.off_hot_tasks);
+  U128* hot_part = (U128*)(ws_base + ws.off_hot_part);
   hipError_t e;
   if ((e = hipMemsetAsync(counts, 0, ws.K * 4, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(bsum, 0, ws.K * 128, stream)) != hipSuccess) return e;   // empty buckets = identity
+  if ((e = hipMemsetAsync(misc, 0, 64, stream)) != hipSuccess) return e;           // misc[0] = hot task counter
   const size_t lds = (size_t)g.B * 4;
   if (lds > 48 * 1024) {
     if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -564,9 +638,13 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
                      sref, skey, offsets, ws.K, ws.T, bsum, head, tail);
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+  hipLaunchKernelGGL(msm_hot_tasks_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K,
+                     ws.T, hot_slot, hot_tasks, misc, ws.max_tasks);
+  hipLaunchKernelGGL(msm_hot_reduce_kernel<CV>, dim3(1024), dim3(64), 0, stream, offsets, ws.T, hot_slot, hot_tasks,
+                     misc, ws.max_tasks, head, tail, hot_part);
   const size_t fix_threads = ws.K << ws.log_g;
   hipLaunchKernelGGL(msm_fixup_kernel<CV>, dim3((unsigned)((fix_threads + 255) / 256)), dim3(256), 0, stream, offsets,
-                     ws.K, ws.T, ws.log_g, bsum, head, tail, xsum);
+                     ws.K, ws.T, ws.log_g, bsum, head, tail, hot_slot, hot_part, xsum);
   hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, xsum, weighted,
                      ws.K, g.B - 1);
   if (ws.lvl1 == 1) {

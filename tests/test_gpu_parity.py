@@ -169,6 +169,35 @@ def test_msm_hot_bucket_all_ones(h2):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n", [1 << 16, 1 << 18])
+def test_msm_degenerate_columns_take_the_hierarchical_path(h2, n):
+    """a permutation grand product that is 1 on almost every row, a 0/1 selector, two repeated values mixed with
+    dense rows: buckets with tens of thousands of entries (more than MSM_HOT_SPAN chunk pieces)"""
+    curve = "bn254"
+    f = scalar_field(curve)
+    b = rand_bases(curve, n)
+    bases = h2.Bases(curve, b)
+    try:
+        one = np.array(f.limbs(1), dtype=np.uint64)
+        ones = np.tile(one, (n, 1))
+        ones[-6:] = rand_scalars(curve, 6, seed=77)                 # blinding rows
+        sel = np.zeros((n, 4), dtype=np.uint64)
+        sel[::3] = one                                             # 0/1 selector
+        two_vals = np.tile(np.array(f.limbs(0x1234567 << 40), dtype=np.uint64), (n, 1))
+        two_vals[1::2] = np.array(f.limbs(f.p - 5), dtype=np.uint64)
+        mixed = rand_scalars(curve, n, seed=78)
+        mixed[: n // 2] = one
+        cols = [ones, sel, two_vals, mixed]
+        got = bases.msm_batch(cols)
+        for j, col in enumerate(cols):
+            want = norm(curve, O.best_multiexp(CID[curve], col, b, threads=8))
+            assert np.array_equal(got[j], want), j
+        # one column alone (different chunk size T than the batch)
+        assert np.array_equal(norm(curve, bases.msm(ones)), norm(curve, O.best_multiexp(CID[curve], ones, b, threads=8)))
+    finally:
+        bases.release()
+
+
 def test_msm_sparse_witness_shape(h2):
     """zero except 64 dense rows at the top and 6 at the bottom (SURVEY.md section 8(d) 'sparse')."""
     curve, n = "bn254", 1 << 12
