@@ -234,6 +234,17 @@ def main():
         torch.cuda.synchronize()
         phases_ms[name] = round(e0.elapsed_time(e1) / 3, 4)
 
+    # NTT roofline: algorithmic bytes = 64 B per element per pass (SURVEY.md 8(d) bytes_ntt = m*n*64, here per
+    # pass of the multi-pass transform); passes = ceil(log_n / 10)
+    roofline_ntt = None
+    if ntt_bufs:
+        ntt_bytes = sum(m * (1 << lg) * 64 * ((lg + 9) // 10) for _, lg, m, _ in ntt_bufs)
+        ach = ntt_bytes / (phases_ms["ntt"] * 1e-3) / 1e9
+        roofline_ntt = {"bound": "hbm", "kernel": "ntt_pass_kernel (all launches of the step's NTTs)",
+                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_step": ntt_bytes, "ms_per_step": phases_ms["ntt"]}
+
     ops_step = n_msm * ops_msm(n) + sum(m * ops_ntt(1 << lg) for _, lg, m, _ in ntt_bufs)
     value = world * ops_step * args.steps / dt
 
@@ -276,7 +287,8 @@ def main():
                        "parallelism": "columns sharded over %d rank(s), 1 all-gather/step" % world,
                        "msm_window_bits": plan["window_bits"], "msm_windows": plan["windows"],
                        "msm_table_bytes": plan["table_bytes"]},
-            "roofline": roofline, "cpu_baseline": cpu, "proof_gen": proof_gen, "phases_ms": phases_ms,
+            "roofline": roofline, "roofline_ntt": roofline_ntt, "cpu_baseline": cpu, "proof_gen": proof_gen,
+            "phases_ms": phases_ms,
             "field_ops_per_step": ops_step,
         }
         print(json.dumps(out))
