@@ -25,12 +25,12 @@
 //    tree (buckets cut into hundreds of pieces -- degenerate columns -- first go through a
 //    wave-per-128-pieces reduction), then the bucket weights (b+1) and a two-level tree sum.
 #pragma once
-#include "h2_curve.hpp"
+#include "h2_curve_quad.hpp"
 
 namespace h2 {
 
 constexpr uint32_t MSM_SIGN = 0x80000000u;
-constexpr uint32_t MSM_TREE_SEG = 128;    // points summed by one wave of the first tree level
+constexpr uint32_t MSM_TREE_SEG = 64;     // points summed by one wave (16 quads) of the first tree level
 constexpr uint32_t MSM_MAX_WINDOWS = 48;
 constexpr uint32_t MSM_HOT_SPAN = 256;    // keys cut into more pieces than this take the hierarchical path
 constexpr uint32_t MSM_HOT_SEG = 128;     // pieces summed by one wave of msm_hot_reduce_kernel
@@ -346,27 +346,30 @@ msm_hot_tasks_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T,
   hot_slot[key] = slot;
 }
 
-// one wave per task: sum MSM_HOT_SEG consecutive pieces of a hot key (2 per lane, then a 6-level shuffle tree)
+// one wave per task = 16 quads (4 lanes per point, h2_curve_quad.hpp): quad g folds pieces g, g+16, ... of the
+// task's MSM_HOT_SEG pieces, then a 4-level shuffle tree across the quads
 template <class CV>
 __global__ void __launch_bounds__(64)
 msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const uint32_t* __restrict__ hot_slot,
                       const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t max_tasks,
                       const U128* __restrict__ head, const U128* __restrict__ tail, U128* __restrict__ hot_part) {
   const uint32_t ntask = min(*task_count, max_tasks);
+  const uint32_t quad = threadIdx.x >> 2;
   for (uint32_t t = blockIdx.x; t < ntask; t += gridDim.x) {
     const uint32_t key = tasks[2 * t], q = tasks[2 * t + 1];
     const uint32_t s = offsets[key], e = offsets[key + 1];
     const uint32_t j0 = s / T, span = (e - 1) / T - j0 + 1;
     const uint32_t lo = q * MSM_HOT_SEG, hi = min(span, lo + MSM_HOT_SEG);
     Xyzz<CV> a = Xyzz<CV>::identity();
-    for (uint32_t p = lo + threadIdx.x; p < hi; p += 64) a = xyzz_add(a, msm_piece<CV>(head, tail, s, j0, T, p));
-    for (uint32_t d = 32; d > 0; d >>= 1) a = xyzz_add(a, xyzz_shfl_down(a, d));
+    for (uint32_t p = lo + quad; p < hi; p += 16) a = xyzz_add_quad(a, msm_piece<CV>(head, tail, s, j0, T, p));
+    for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_add_quad(a, xyzz_shfl_down(a, d));
     if (threadIdx.x == 0) xyzz_store<CV>(hot_part + 8 * (size_t)(hot_slot[key] + q), a);
   }
 }
 
-// Fix-up: G lanes (G = 2^log_g <= 64) per key sum the key's pieces when its list was cut across chunks;
-// lane 0 writes xsum[key] (the bucket's point sum).
+// Fix-up: G lanes = G/4 quads per key (G = 2^log_g, 4 <= G <= 64; 4 lanes per point, h2_curve_quad.hpp).  The
+// quads of a key share out its pieces (or its hot partials), then a shuffle tree across the quads; lane 0 writes
+// xsum[key], the bucket's point sum.
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g,
@@ -376,6 +379,7 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> log_g;
   const uint32_t lane = (uint32_t)gt & (G - 1);
+  const uint32_t quad = lane >> 2, nquad = G >> 2;
   // all lanes of a wave stay in the shuffle tree together; out-of-range keys work on identities
   const bool live = key < K;
   Xyzz<CV> x = Xyzz<CV>::identity();
@@ -384,29 +388,28 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
     if (e > s) {
       const uint32_t j0 = s / T, j1 = (e - 1) / T;
       if (j0 == j1) {
-        if (lane == 0) x = xyzz_load<CV>(bucket_sum + 8 * key);
+        if (quad == 0) x = xyzz_load<CV>(bucket_sum + 8 * key);
       } else if (hot_slot[key] != MSM_NOT_HOT) {
         const uint32_t nseg = (j1 - j0 + 1 + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
         const U128* part = hot_part + 8 * (size_t)hot_slot[key];
-        for (uint32_t q = lane; q < nseg; q += G) x = xyzz_add(x, xyzz_load<CV>(part + 8 * (size_t)q));
+        for (uint32_t q = quad; q < nseg; q += nquad) x = xyzz_add_quad(x, xyzz_load<CV>(part + 8 * (size_t)q));
       } else {
-        for (uint32_t p = lane; p <= j1 - j0; p += G) x = xyzz_add(x, msm_piece<CV>(head, tail, s, j0, T, p));
+        for (uint32_t p = quad; p <= j1 - j0; p += nquad) x = xyzz_add_quad(x, msm_piece<CV>(head, tail, s, j0, T, p));
       }
     }
   }
-  for (uint32_t d = G >> 1; d > 0; d >>= 1) {
-    Xyzz<CV> y = xyzz_shfl_down(x, d);
-    x = xyzz_add(x, y);
-  }
+  for (uint32_t d = G >> 1; d >= 4; d >>= 1) x = xyzz_add_quad(x, xyzz_shfl_down(x, d));
   if (live && lane == 0) xyzz_store<CV>(xsum + 8 * key, x);
 }
 
-// Bucket weights: weighted[key] = (bucket + 1) * xsum[key], one thread per key (MSB-first double-and-add).
+// Bucket weights: weighted[key] = (bucket + 1) * xsum[key], one QUAD per key (MSB-first double-and-add with the
+// 4-lanes-per-point arithmetic: a doubling is 3 multiplication levels deep, an addition 4).
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_weight_kernel(const U128* __restrict__ xsum, U128* __restrict__ weighted, size_t K, uint32_t bucket_mask) {
-  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= K) return;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t key = gt >> 2;
+  if (key >= K) return;                       // whole quads leave together (K * 4 threads are launched)
   Xyzz<CV> x = xyzz_load<CV>(xsum + 8 * key);
   Xyzz<CV> r = Xyzz<CV>::identity();
   if (!x.is_identity()) {
@@ -414,17 +417,17 @@ msm_weight_kernel(const U128* __restrict__ xsum, U128* __restrict__ weighted, si
     const int top = 31 - __clz(k);
     r = x;
     for (int bit = top - 1; bit >= 0; bit--) {
-      r = xyzz_double(r);
-      if ((k >> bit) & 1) r = xyzz_add(r, x);
+      r = xyzz_double_quad(r);
+      if ((k >> bit) & 1) r = xyzz_add_quad(r, x);
     }
   }
-  xyzz_store<CV>(weighted + 8 * key, r);
+  if ((gt & 3) == 0) xyzz_store<CV>(weighted + 8 * key, r);
 }
 
 // ---- tree sum: out[col][blockIdx.x] = sum of the `seg` points in[col][blockIdx.x*seg ...] -------------
-// One 64-lane wave per block (so every wave gets a SIMD of its own on a different CU): lanes stride over the
-// segment, then a 6-level DPP shuffle tree.  Level 1 uses seg = 128 (one load + one add + tree = 7 dependent
-// additions), level 2 sums the B/128 partials of a column in one wave.
+// One 64-lane wave per block (so every wave gets a SIMD of its own on a different CU) = 16 quads with 4 lanes per
+// point: quad g folds points g, g+16, ..., then a 4-level shuffle tree across the quads.  Level 1 uses seg = 64,
+// level 2 sums the B/64 partials of a column in one wave.
 template <class CV>
 __global__ void __launch_bounds__(64)
 msm_tree_sum_kernel(const U128* __restrict__ in, U128* __restrict__ out, uint32_t count /* per column */,
@@ -433,9 +436,9 @@ msm_tree_sum_kernel(const U128* __restrict__ in, U128* __restrict__ out, uint32_
   const uint32_t base = blockIdx.x * seg;
   const uint32_t end = min(base + seg, count);
   Xyzz<CV> a = Xyzz<CV>::identity();
-  for (uint32_t idx = base + threadIdx.x; idx < end; idx += 64)
-    a = xyzz_add(a, xyzz_load<CV>(in + 8 * ((size_t)col * count + idx)));
-  for (uint32_t d = 32; d > 0; d >>= 1) a = xyzz_add(a, xyzz_shfl_down(a, d));
+  for (uint32_t idx = base + (threadIdx.x >> 2); idx < end; idx += 16)
+    a = xyzz_add_quad(a, xyzz_load<CV>(in + 8 * ((size_t)col * count + idx)));
+  for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_add_quad(a, xyzz_shfl_down(a, d));
   if (threadIdx.x == 0) xyzz_store<CV>(out + 8 * ((size_t)col * out_per_col + blockIdx.x), a);
 }
 
@@ -548,10 +551,13 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   // lanes per key in the fix-up: as many as the pieces need, but no more than keeps the whole launch
   // around 128k threads (wider groups waste most of their lanes in the shuffle tree), and at least 8 when
   // lists are cut at all
+  // the fix-up gives every key G lanes = G/4 quads (4 lanes per point); as many quads as the pieces need, but the
+  // whole launch stays around 256k threads
   uint32_t lg = 0;
-  while ((1u << lg) < span && lg < 6) lg++;
-  uint32_t cap = 3;
-  while (cap < 6 && (ws.K << (cap + 1)) <= 131072) cap++;
+  while ((1u << lg) < span && lg < 4) lg++;       // quads per key
+  lg += 2;                                        // lanes per key
+  uint32_t cap = 2;
+  while (cap < 6 && (ws.K << (cap + 1)) <= 262144) cap++;
   if (lg > cap) lg = cap;
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
@@ -645,8 +651,8 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   const size_t fix_threads = ws.K << ws.log_g;
   hipLaunchKernelGGL(msm_fixup_kernel<CV>, dim3((unsigned)((fix_threads + 255) / 256)), dim3(256), 0, stream, offsets,
                      ws.K, ws.T, ws.log_g, bsum, head, tail, hot_slot, hot_part, xsum);
-  hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, xsum, weighted,
-                     ws.K, g.B - 1);
+  hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((unsigned)((ws.K * 4 + 255) / 256)), dim3(256), 0, stream, xsum,
+                     weighted, ws.K, g.B - 1);
   if (ws.lvl1 == 1) {
     hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(64), 0, stream, weighted, tree2, g.B, g.B,
                        1u);
