@@ -10,7 +10,11 @@
 // Here the four lanes of a quad hold the same two points; at each level every lane selects the operands of ITS
 // product (v_cndmask on the lane's role), all four execute the same fe_mul, and the results are passed around with
 // v_mov_b32 quad_perm broadcasts (one VALU instruction per word, no LDS).  ~2000 instructions per addition instead
-// of ~5600: dependent additions complete 2.8x sooner, doublings (depth 3 instead of 9) 2.3x sooner.
+// of ~5600: dependent additions complete sooner.  Measured on MI355X (Poseidon k = 16 bench, per MSM phase): bucket
+// weights 192 -> 131 us, bucket tree 190 -> 131 us.  The fix-up kernel was measured too and stays on one lane per
+// point (190 us against 232 us with quads: with four times the lanes it leaves the one-wave-per-SIMD regime, where
+// the quad form's ~1.4x instruction overhead per point costs more than its shorter chain saves).  A non-inlined
+// multiplier (to shrink the ~45 KB of straight-line code per addition) was measured as well: 5-8 % slower.
 //
 // Contract: a and b are REPLICATED across the quad (all four lanes hold identical values) and so is the result.
 // All four lanes of a quad must be active and take the same branches (they do: the data is replicated).
