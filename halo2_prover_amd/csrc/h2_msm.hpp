@@ -17,7 +17,7 @@
 //    bit 31 of the sorted entry and negates y on the fly.
 //  * sort by bucket: digits kernel (LDS histogram per block, one global atomic per block and
 //    bucket) -> exclusive scan -> scatter (LDS cursors), giving per bucket the contiguous list
-//    of table indices to add.
+//    of table indices to add (4 bytes per entry; the entry's bucket is implied by `offsets`).
 //  * accumulate = segmented reduction with perfect load balance: every thread adds exactly T
 //    consecutive sorted entries (mixed XYZZ additions, 8M + 2S) whatever bucket they belong
 //    to, writes complete runs straight to the bucket and its cut-off head / tail runs to
@@ -213,11 +213,12 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
 
 // ---- scatter: same tiling as the digits kernel.  LDS histogram of the tile, one global atomic per
 // non-empty bucket reserves the tile's range in the bucket's list, then LDS cursors place the entries.
-// sorted_ref[pos] = (w * n_bases + i) | sign ; sorted_key[pos] = col*B + bucket
+// sorted_ref[pos] = (w * n_bases + i) | sign.  Only ONE word per entry is written: every scattered 4-byte store
+// costs a 64-byte sector at the memory side (measured: 8x write amplification), so the entry's key is not stored --
+// the accumulate kernel recovers it from `offsets`.
 static __global__ void __launch_bounds__(256)
 msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
-                   uint32_t* __restrict__ sorted_ref, uint32_t* __restrict__ sorted_key, uint32_t n, uint32_t n_bases,
-                   uint32_t tile, MsmGeom g) {
+                   uint32_t* __restrict__ sorted_ref, uint32_t n, uint32_t n_bases, uint32_t tile, MsmGeom g) {
   extern __shared__ uint32_t hist[];
   const uint32_t col = blockIdx.y;
   for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = 0;
@@ -244,7 +245,6 @@ msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ c
         const uint32_t b = (enc & ~MSM_SIGN) - 1;
         const uint32_t pos = atomicAdd(&hist[b], 1u);
         sorted_ref[pos] = (w * n_bases + i) | (enc & MSM_SIGN);
-        sorted_key[pos] = col * g.B + b;
       }
     }
   }
@@ -258,35 +258,57 @@ __device__ __forceinline__ Affine<CV> msm_fetch(const U128* __restrict__ table, 
   return p;
 }
 
-// Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device.
-// A run (maximal stretch of one key inside the chunk) that holds the key's whole list goes to
-// bucket_sum[key]; a cut-off first run goes to head[t], a cut-off last run to tail[t].
+// chunk_first[t] = the key that owns sorted entry t*T (the first entry of chunk t): one thread per key writes the
+// chunks that START inside its list.  Each chunk start lies in exactly one non-empty list, so every slot below
+// ceil(E / T) gets exactly one writer.
+static __global__ void __launch_bounds__(256)
+msm_chunk_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t* __restrict__ chunk_first) {
+  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= K) return;
+  const uint32_t s = offsets[key], e = offsets[key + 1];
+  for (uint32_t j = (s + T - 1) / T; (uint64_t)j * T < e; j++) chunk_first[j] = (uint32_t)key;
+}
+
+// Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device; T is a multiple of 4 and
+// the refs are read as 16-byte vectors.  A run (maximal stretch of one key inside the chunk) that holds the key's
+// whole list goes to bucket_sum[key]; a cut-off first run goes to head[t], a cut-off last run to tail[t].
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ sorted_ref,
-                 const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ offsets, size_t K, uint32_t T,
+                 const uint32_t* __restrict__ chunk_first, const uint32_t* __restrict__ offsets, size_t K, uint32_t T,
                  U128* __restrict__ bucket_sum, U128* __restrict__ head, U128* __restrict__ tail) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t E = offsets[K];
   const uint64_t lo64 = (uint64_t)t * T;
   if (lo64 >= E) return;
   const uint32_t lo = (uint32_t)lo64, hi = (uint32_t)min((uint64_t)E, lo64 + T);
-  uint32_t key = sorted_key[lo];
+  uint32_t key = chunk_first[t];
+  uint32_t next = offsets[key + 1];          // first entry of the following list
   bool first = true;
   Xyzz<CV> a = Xyzz<CV>::identity();
-  for (uint32_t e = lo; e < hi; e++) {
-    const uint32_t k = sorted_key[e];
-    if (k != key) {
-      // the run of `key` ended inside the chunk
-      if (first && offsets[key] != lo) xyzz_store<CV>(head + 8 * (size_t)t, a);
-      else xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
-      first = false;
-      a = Xyzz<CV>::identity();
-      key = k;
+  for (uint32_t e4 = lo; e4 < hi; e4 += 4) {
+    const U128 quad = *reinterpret_cast<const U128*>(sorted_ref + e4);   // 16-byte aligned: lo and e4 are multiples of 4
+    const uint32_t refs[4] = {quad.x, quad.y, quad.z, quad.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t e = e4 + k;
+      if (e < hi) {
+        if (e >= next) {
+          // the run of `key` ended inside the chunk
+          if (first && offsets[key] != lo) xyzz_store<CV>(head + 8 * (size_t)t, a);
+          else xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
+          first = false;
+          a = Xyzz<CV>::identity();
+          do {                                  // skip empty lists
+            key++;
+            next = offsets[key + 1];
+          } while (e >= next);
+        }
+        a = xyzz_add_affine(a, msm_fetch<CV>(table, refs[k]));
+      }
     }
-    a = xyzz_add_affine(a, msm_fetch<CV>(table, sorted_ref[e]));
   }
-  const bool ends_here = offsets[key + 1] == hi;
+  const bool ends_here = next == hi;
   const bool starts_here = !first || offsets[key] == lo;
   if (starts_here && ends_here) xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
   else if (first) xyzz_store<CV>(head + 8 * (size_t)t, a);   // one run spanning the whole chunk, or a cut first run
@@ -543,6 +565,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   uint64_t T = (ws.E + 262143) / 262144;
   if (T < 8) T = 8;
   if (T > 64) T = 64;
+  T = (T + 3) & ~(uint64_t)3;                     // the accumulate kernel reads refs four at a time
   ws.T = (uint32_t)T;
   ws.nchunks = (ws.E + T - 1) / T;
   // pieces per key ~ list length / T + 1
@@ -574,8 +597,8 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
   ws.off_cursor = o; o = h2_align256(o + ws.K * 4);
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
-  ws.off_ref = o; o = h2_align256(o + ws.E * 4);
-  ws.off_key = o; o = h2_align256(o + ws.E * 4);
+  ws.off_ref = o; o = h2_align256(o + ws.E * 4 + 16);             // + one vector of slack for the last 16-byte read
+  ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
   ws.off_misc = o; o = h2_align256(o + 64);
   ws.off_bsum = o; o = h2_align256(o + ws.K * 128);
   ws.off_head = o; o = h2_align256(o + ws.nchunks * 128);
@@ -607,7 +630,7 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   uint32_t* cursor = (uint32_t*)(ws_base + ws.off_cursor);
   uint32_t* blocksums = (uint32_t*)(ws_base + ws.off_blocksums);
   uint32_t* sref = (uint32_t*)(ws_base + ws.off_ref);
-  uint32_t* skey = (uint32_t*)(ws_base + ws.off_key);
+  uint32_t* chunk_first = (uint32_t*)(ws_base + ws.off_key);
   uint32_t* misc = (uint32_t*)(ws_base + ws.off_misc);
   U128* bsum = (U128*)(ws_base + ws.off_bsum);
   U128* head = (U128*)(ws_base + ws.off_head);
@@ -637,11 +660,13 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      cursor, ws.K);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(256), lds, stream, digits, cursor, sref, skey,
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(256), lds, stream, digits, cursor, sref,
                      (uint32_t)n, n_bases, ws.tile, g);
+  hipLaunchKernelGGL(msm_chunk_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K,
+                     ws.T, chunk_first);
   if (ev_start) (void)hipEventRecord(ev_start, stream);
   hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
-                     sref, skey, offsets, ws.K, ws.T, bsum, head, tail);
+                     sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   hipLaunchKernelGGL(msm_hot_tasks_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K,
                      ws.T, hot_slot, hot_tasks, misc, ws.max_tasks);
