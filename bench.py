@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--workload", default="poseidon", choices=["poseidon", "msm", "ntt"],
                     help="poseidon = the proof-shaped MSM+NTT mix (default); msm / ntt = one kernel family only")
     ap.add_argument("--msm-cols", type=int, default=1, help="columns per launch for --workload msm")
+    ap.add_argument("--ntt-cols", type=int, default=1, help="columns per launch for --workload ntt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proof", action="store_true", help="skip the end-to-end Poseidon proof (proof-gen ms)")
     args = ap.parse_args()
@@ -174,7 +175,7 @@ def main():
     if args.workload == "poseidon":
         ntts = [(k, 7, True), (k + ext, 7, False), (k + ext, 1, True)]
     elif args.workload == "ntt":
-        ntts = [(k, 1, False)]
+        ntts = [(k, args.ntt_cols, False)]
     else:
         ntts = []
     ntt_bufs = []

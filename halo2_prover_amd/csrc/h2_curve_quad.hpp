@@ -35,14 +35,16 @@ __device__ __forceinline__ Fe<FP> quad_bcast(const Fe<FP>& a) {
   for (int i = 0; i < 8; i++) r.v[i] = quad_bcast_u32<R>(a.v[i]);
   return r;
 }
-// the operand of lane role q among four candidates
+// the operand of lane role q among four candidates.  Written as mask arithmetic ((m & a) | (~m & b) is one
+// v_bfi_b32): as `q == 0 ? a0 : ...` the compiler turned every word into exec-mask branches.
+__device__ __forceinline__ uint32_t quad_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
 template <class FP>
 __device__ __forceinline__ Fe<FP> quad_select(uint32_t q, const Fe<FP>& a0, const Fe<FP>& a1, const Fe<FP>& a2,
                                               const Fe<FP>& a3) {
   Fe<FP> r;
-  const bool is0 = q == 0, is1 = q == 1, is2 = q == 2;
+  const uint32_t m1 = 0u - (q & 1u), m2 = 0u - ((q >> 1) & 1u);
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = is0 ? a0.v[i] : (is1 ? a1.v[i] : (is2 ? a2.v[i] : a3.v[i]));
+  for (int i = 0; i < 8; i++) r.v[i] = quad_bfi(m2, quad_bfi(m1, a3.v[i], a2.v[i]), quad_bfi(m1, a1.v[i], a0.v[i]));
   return r;
 }
 

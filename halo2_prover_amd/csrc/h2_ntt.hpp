@@ -1,4 +1,4 @@
-// h2_ntt.hpp -- radix-2 NTT over 256-bit Montgomery fields for gfx950.
+// h2_ntt.hpp -- NTT over 256-bit Montgomery fields for gfx950 (radix-2 stages fused in pairs).
 //
 // Device replacement for halo2_proofs::arithmetic::best_fft / recursive_butterfly_arithmetic
 // (halo2_proofs @6b43b6b, src/arithmetic.rs -- un-vendored; algorithm restated in SURVEY.md
@@ -122,36 +122,61 @@ ntt_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U128*
   }
   __syncthreads();
 
-  // butterfly stages
-  const uint32_t nbf = RC >> 1;
-  for (uint32_t s = 0; s < P.log_r; s++) {
-    const uint32_t half = 1u << s;
-    for (uint32_t w = tid; w < nbf; w += nthr) {
+  // butterfly stages.  Two radix-2 stages (s, s+1) are done per trip through LDS: a thread holds the four elements
+  // base + {0, 1, 2, 3} * 2^s in registers, so the tile crosses LDS (and the block synchronises) log2(R)/2 times
+  // instead of log2(R).  An odd log2(R) starts with the lone stage 0, whose twiddles are all 1.
+  auto lds_get = [&](uint32_t i) {
+    const U128 a0 = tile0[i], a1 = tile1[i];
+    Fe<FP> x;
+    x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w;
+    x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
+    return x;
+  };
+  auto lds_put = [&](uint32_t i, const Fe<FP>& u) {
+    tile0[i] = U128{u.v[0], u.v[1], u.v[2], u.v[3]};
+    tile1[i] = U128{u.v[4], u.v[5], u.v[6], u.v[7]};
+  };
+  auto tw_get = [&](uint32_t i) {
+    const U128 t0 = twl0[i], t1 = twl1[i];
+    Fe<FP> t;
+    t.v[0] = t0.x; t.v[1] = t0.y; t.v[2] = t0.z; t.v[3] = t0.w;
+    t.v[4] = t1.x; t.v[5] = t1.y; t.v[6] = t1.z; t.v[7] = t1.w;
+    return t;
+  };
+  uint32_t s = 0;
+  if (P.log_r & 1) {
+    for (uint32_t w = tid; w < (RC >> 1); w += nthr) {
       const uint32_t cc = w & (C - 1), b = w >> P.log_c;
-      const uint32_t pos = b & (half - 1), grp = b >> s;
-      const uint32_t i0 = (((grp << (s + 1)) + pos) << P.log_c) + cc;
-      const uint32_t i1 = i0 + (half << P.log_c);
-      Fe<FP> x, y;
-      {
-        U128 a0 = tile0[i0], a1 = tile1[i0], b0 = tile0[i1], b1 = tile1[i1];
-        x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w;
-        x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
-        y.v[0] = b0.x; y.v[1] = b0.y; y.v[2] = b0.z; y.v[3] = b0.w;
-        y.v[4] = b1.x; y.v[5] = b1.y; y.v[6] = b1.z; y.v[7] = b1.w;
+      const uint32_t i0 = (b << (P.log_c + 1)) + cc, i1 = i0 + C;
+      const Fe<FP> x = lds_get(i0), y = lds_get(i1);
+      lds_put(i0, fe_add(x, y));
+      lds_put(i1, fe_sub(x, y));
+    }
+    __syncthreads();
+    s = 1;
+  }
+  for (; s < P.log_r; s += 2) {
+    const uint32_t h = 1u << s;
+    for (uint32_t w = tid; w < (RC >> 2); w += nthr) {
+      const uint32_t cc = w & (C - 1), b = w >> P.log_c;
+      const uint32_t pos = b & (h - 1), grp = b >> s;
+      const uint32_t i0 = (((grp << (s + 2)) + pos) << P.log_c) + cc;
+      const uint32_t step = h << P.log_c;
+      Fe<FP> e0 = lds_get(i0), e1 = lds_get(i0 + step), e2 = lds_get(i0 + 2 * step), e3 = lds_get(i0 + 3 * step);
+      const uint32_t tb = pos << (P.log_r - 2 - s);
+      if (s != 0) {                      // s == 0: pos == 0, the twiddles of stage s and of the pair (e0, e2) are 1
+        const Fe<FP> ta = tw_get(pos << (P.log_r - 1 - s));
+        e1 = fe_mul(e1, ta);
+        e3 = fe_mul(e3, ta);
       }
-      if (pos != 0) {
-        const uint32_t ti = pos << (P.log_r - 1 - s);
-        U128 t0 = twl0[ti], t1 = twl1[ti];
-        Fe<FP> t;
-        t.v[0] = t0.x; t.v[1] = t0.y; t.v[2] = t0.z; t.v[3] = t0.w;
-        t.v[4] = t1.x; t.v[5] = t1.y; t.v[6] = t1.z; t.v[7] = t1.w;
-        y = fe_mul(y, t);
-      }
-      Fe<FP> u = fe_add(x, y), v = fe_sub(x, y);
-      tile0[i0] = U128{u.v[0], u.v[1], u.v[2], u.v[3]};
-      tile1[i0] = U128{u.v[4], u.v[5], u.v[6], u.v[7]};
-      tile0[i1] = U128{v.v[0], v.v[1], v.v[2], v.v[3]};
-      tile1[i1] = U128{v.v[4], v.v[5], v.v[6], v.v[7]};
+      const Fe<FP> a0 = fe_add(e0, e1), a1 = fe_sub(e0, e1);
+      Fe<FP> a2 = fe_add(e2, e3), a3 = fe_sub(e2, e3);
+      if (s != 0) a2 = fe_mul(a2, tw_get(tb));
+      a3 = fe_mul(a3, tw_get(tb + (R >> 2)));
+      lds_put(i0, fe_add(a0, a2));
+      lds_put(i0 + step, fe_add(a1, a3));
+      lds_put(i0 + 2 * step, fe_sub(a0, a2));
+      lds_put(i0 + 3 * step, fe_sub(a1, a3));
     }
     __syncthreads();
   }
@@ -231,7 +256,7 @@ inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R,
     const uint32_t rc = 1u << (P.log_r + lc);
     pl.lds_bytes[p] = ((size_t)rc + ((size_t)1 << P.log_r) / 2) * 32;
     if (pl.lds_bytes[p] < 64) pl.lds_bytes[p] = 64;
-    uint32_t thr = rc / 2;
+    uint32_t thr = rc / 4;                      // one radix-4 butterfly per thread and double stage
     if (thr < 64) thr = 64;
     if (thr > 1024) thr = 1024;
     pl.threads[p] = thr;
