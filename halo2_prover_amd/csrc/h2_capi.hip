@@ -343,6 +343,42 @@ int h2_msm_plan(uint64_t handle, h2_msm_plan_t* out) {
   return H2_OK;
 }
 
+// Columns per launch: the sort indexes its m * W * n entries with 32 bits, so a wide batch of long columns
+// (2^24 rows x 8 columns) goes through in groups of columns, one after the other on the same stream and workspace.
+// H2_MSM_MAX_ENTRIES lowers the limit (tests use it to reach the grouped path at small sizes).
+static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
+  uint64_t limit = (1ull << 31) - 1;
+  if (const char* ov = getenv("H2_MSM_MAX_ENTRIES")) {
+    const uint64_t v = strtoull(ov, nullptr, 10);
+    if (v > 0 && v < limit) limit = v;
+  }
+  const uint64_t per_col = (uint64_t)be.geom.W * n;
+  uint64_t by_entries = limit / per_col;
+  const uint64_t by_keys = ((1ull << 31) - 1) / be.geom.B;
+  return (size_t)(by_entries < by_keys ? by_entries : by_keys);   // 0: a single column is already too long
+}
+
+// m columns at d_scalars (column stride n) -> m results at d_out (96-byte Jacobian or 64-byte affine), enqueued
+static int msm_device_run(int curve, const BasesEntry& be, const void* d_scalars, size_t n, size_t m, void* d_out,
+                          bool affine_out, hipStream_t stream) {
+  const size_t group = msm_cols_per_launch(be, n);
+  if (group == 0) return H2_EINVAL;
+  const size_t out_sz = affine_out ? 64 : 96;
+  const CurveOps* ops = ops_of(curve);
+  for (size_t j0 = 0; j0 < m; j0 += group) {
+    const size_t mm = m - j0 < group ? m - j0 : group;
+    MsmWorkspace ws;
+    int rc = msm_enqueue(curve, be, (const char*)d_scalars + j0 * n * 32, n, mm, stream, &ws);
+    if (rc != H2_OK) return rc;
+    const void* src = (char*)g_ctx.ws + ws.off_tree2;
+    void* dst = (char*)d_out + j0 * out_sz;
+    hipError_t e = affine_out ? ops->to_affine(src, dst, (uint32_t)mm, stream)
+                              : ops->to_jacobian(src, dst, (uint32_t)mm, stream);
+    if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
+  }
+  return H2_OK;
+}
+
 int h2_msm_device(h2_curve_t curve, uint64_t handle, const void* d_scalars, size_t n, size_t m, void* d_out_jac,
                   void* stream_) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -355,12 +391,7 @@ int h2_msm_device(h2_curve_t curve, uint64_t handle, const void* d_scalars, size
     H2_TRY(hipMemsetAsync(d_out_jac, 0, m * 96, stream));
     return H2_OK;
   }
-  MsmWorkspace ws;
-  rc = msm_enqueue((int)curve, *be, d_scalars, n, m, stream, &ws);
-  if (rc != H2_OK) return rc;
-  hipError_t e = ops_of((int)curve)->to_jacobian((char*)g_ctx.ws + ws.off_tree2, d_out_jac, (uint32_t)m, stream);
-  if (e != hipSuccess) return dev_fail(e, "msm_to_jacobian_kernel");
-  return H2_OK;
+  return msm_device_run((int)curve, *be, d_scalars, n, m, d_out_jac, false, stream);
 }
 
 static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* cols, size_t n, size_t m, uint64_t* out,
@@ -383,17 +414,9 @@ static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* co
   for (size_t j = 0; j < m; j++)
     H2_TRY(hipMemcpyAsync((char*)g_ctx.stage + j * col_bytes, cols[j], col_bytes, hipMemcpyHostToDevice,
                           g_ctx.stream));
-  MsmWorkspace ws;
-  rc = msm_enqueue((int)curve, *be, g_ctx.stage, n, m, g_ctx.stream, &ws);
-  if (rc != H2_OK) return rc;
   void* d_res = (char*)g_ctx.stage + res_off;
-  {
-    const void* src = (char*)g_ctx.ws + ws.off_tree2;
-    const CurveOps* ops = ops_of((int)curve);
-    hipError_t e = affine_out ? ops->to_affine(src, d_res, (uint32_t)m, g_ctx.stream)
-                              : ops->to_jacobian(src, d_res, (uint32_t)m, g_ctx.stream);
-    if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
-  }
+  rc = msm_device_run((int)curve, *be, g_ctx.stage, n, m, d_res, affine_out, g_ctx.stream);
+  if (rc != H2_OK) return rc;
   H2_TRY(hipMemcpyAsync(out, d_res, m * out_sz, hipMemcpyDeviceToHost, g_ctx.stream));
   H2_TRY(hipStreamSynchronize(g_ctx.stream));
   return H2_OK;

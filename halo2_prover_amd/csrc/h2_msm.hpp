@@ -26,6 +26,7 @@
 //    wave-per-128-pieces reduction), then the bucket weights (b+1) and a two-level tree sum.
 #pragma once
 #include "h2_curve_quad.hpp"
+#include <cstdlib>
 
 namespace h2 {
 
@@ -389,9 +390,9 @@ msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const ui
   }
 }
 
-// Fix-up: G lanes (G = 2^log_g <= 64) per key, one lane per point (measured faster here than the quad form, see
-// h2_curve_quad.hpp).  The lanes share out the key's pieces (or its hot partials), then a shuffle tree; lane 0
-// writes xsum[key], the bucket's point sum.
+// Fix-up: G lanes = G/4 quads per key (G = 2^log_g, 4 <= G <= 64; 4 lanes per point, h2_curve_quad.hpp).  The
+// quads of a key share out its pieces (or its hot partials), then a shuffle tree across the quads; lane 0 writes
+// xsum[key], the bucket's point sum.
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g,
@@ -401,6 +402,7 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> log_g;
   const uint32_t lane = (uint32_t)gt & (G - 1);
+  const uint32_t quad = lane >> 2, nquad = G >> 2;
   // all lanes of a wave stay in the shuffle tree together; out-of-range keys work on identities
   const bool live = key < K;
   Xyzz<CV> x = Xyzz<CV>::identity();
@@ -409,17 +411,17 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
     if (e > s) {
       const uint32_t j0 = s / T, j1 = (e - 1) / T;
       if (j0 == j1) {
-        if (lane == 0) x = xyzz_load<CV>(bucket_sum + 8 * key);
+        if (quad == 0) x = xyzz_load<CV>(bucket_sum + 8 * key);
       } else if (hot_slot[key] != MSM_NOT_HOT) {
         const uint32_t nseg = (j1 - j0 + 1 + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
         const U128* part = hot_part + 8 * (size_t)hot_slot[key];
-        for (uint32_t q = lane; q < nseg; q += G) x = xyzz_add(x, xyzz_load<CV>(part + 8 * (size_t)q));
+        for (uint32_t q = quad; q < nseg; q += nquad) x = xyzz_add_quad(x, xyzz_load<CV>(part + 8 * (size_t)q));
       } else {
-        for (uint32_t p = lane; p <= j1 - j0; p += G) x = xyzz_add(x, msm_piece<CV>(head, tail, s, j0, T, p));
+        for (uint32_t p = quad; p <= j1 - j0; p += nquad) x = xyzz_add_quad(x, msm_piece<CV>(head, tail, s, j0, T, p));
       }
     }
   }
-  for (uint32_t d = G >> 1; d > 0; d >>= 1) x = xyzz_add(x, xyzz_shfl_down(x, d));
+  for (uint32_t d = G >> 1; d >= 4; d >>= 1) x = xyzz_add_quad(x, xyzz_shfl_down(x, d));
   if (live && lane == 0) xyzz_store<CV>(xsum + 8 * key, x);
 }
 
@@ -570,17 +572,13 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.nchunks = (ws.E + T - 1) / T;
   // pieces per key ~ list length / T + 1
   const double span = (double)g.W * (double)n / (double)g.B / (double)T + 1.0;
-  // lanes per key in the fix-up: as many as the pieces need, but no more than keeps the whole launch
-  // around 128k threads (wider groups waste most of their lanes in the shuffle tree), and at least 8 when
-  // lists are cut at all
-  // lanes per key in the fix-up: as many as the pieces need, but no more than keeps the whole launch
-  // around 128k threads (wider groups waste most of their lanes in the shuffle tree), and at least 8 when
-  // lists are cut at all
-  uint32_t lg = 0;
-  while ((1u << lg) < span && lg < 6) lg++;
-  uint32_t cap = 3;
-  while (cap < 6 && (ws.K << (cap + 1)) <= 131072) cap++;
-  if (lg > cap) lg = cap;
+  // quads per key in the fix-up: no more than the pieces need, and few enough that the launch stays around
+  // two waves per SIMD (K * Q * 4 lanes <= 160k): wider groups waste most of their quads in the shuffle tree
+  uint32_t lq = 0;
+  while ((1u << lq) < span && lq < 4) lq++;
+  while (lq > 0 && (ws.K << lq) > 40960) lq--;
+  uint32_t lg = lq + 2;
+  if (const char* ov = getenv("H2_FIXUP_LOG_G")) lg = (uint32_t)atoi(ov);   // tuning aid
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
   size_t tile = (n * m + 1023) / 1024;

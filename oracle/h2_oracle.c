@@ -496,6 +496,23 @@ int h2o_field_op(int fid, int op, const uint64_t *a, const uint64_t *b, uint64_t
   return 0;
 }
 
+/* sum_i coeffs[i] x^i by Horner's rule from the top coefficient down: halo2_proofs @6b43b6b src/arithmetic.rs
+ * `eval_polynomial` (its serial branch; the parallel branch evaluates chunks the same way and recombines them with
+ * powers of x, the same field element).  All values in Montgomery form. */
+int h2o_eval_polynomial(int fid, const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out) {
+  if (fid < 0 || fid > 3) return -1;
+  F f = &H2O_FIELDS[fid];
+  fe acc, xx;
+  memset(&acc, 0, sizeof acc);
+  memcpy(&xx, x, 32);
+  for (size_t i = n; i-- > 0;) {
+    fe_mul(&acc, &acc, &xx, f);
+    fe_add(&acc, &acc, (const fe *)coeffs + i, f);
+  }
+  memcpy(out, &acc, 32);
+  return 0;
+}
+
 /* n field multiplications a[i]*b[i] (for bulk cross-checks) */
 int h2o_field_mul_many(int fid, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
   if (fid < 0 || fid > 3) return -1;

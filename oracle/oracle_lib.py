@@ -42,6 +42,7 @@ def lib():
             "h2o_group_fft": [I, P, P, U],
             "h2o_field_op": [I, I, P, P, P],
             "h2o_field_mul_many": [I, P, P, Z, P],
+            "h2o_eval_polynomial": [I, P, Z, P, P],
             "h2o_to_affine": [I, P, Z, P],
             "h2o_is_on_curve": [I, P, Z],
             "h2o_scalar_mul": [I, P, P, P],
@@ -112,6 +113,14 @@ def field_mul_many(fid, a, b):
     a, b = _u64(a), _u64(b)
     out = np.zeros_like(a)
     assert lib().h2o_field_mul_many(fid, _p(a), _p(b), a.size // 4, _p(out)) == 0
+    return out
+
+
+def eval_polynomial(fid, coeffs, x_mont):
+    """sum_i coeffs[i] x^i (Montgomery limbs in and out)."""
+    coeffs, x = _u64(coeffs), _u64(x_mont)
+    out = np.zeros(4, dtype=np.uint64)
+    assert lib().h2o_eval_polynomial(fid, _p(coeffs), coeffs.size // 4, _p(x), _p(out)) == 0
     return out
 
 

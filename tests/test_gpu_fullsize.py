@@ -4,6 +4,10 @@ golden params fixtures through ParamsKZG.
 * MSM n = 2^20 (config 4): linearity  MSM(a) + MSM(b) = MSM(a + b)  and  MSM(c, c, ..., c) = c * sum(P_i)
   with the sum obtained from an MSM of ones; bases from h2_srs_generate (itself checked against the oracle at
   n = 2^8, whose [s^i]G is pinned by the params sha256).
+* MSM n = 2^24 (config 5's column length; dense and "realistic witness" sparse columns): known answer
+  MSM(a, [s^i]G) = (sum_i a_i s^i) G with the scalar from the oracle's eval_polynomial.
+* column groups: a batch whose sort would not fit 32-bit entry indices is run in groups of columns
+  (H2_MSM_MAX_ENTRIES forces that path at a small size) and must equal the ungrouped result.
 * NTT n = 2^22 (three passes) and the 64-column batch shape of config 5 at reduced n: iNTT(NTT(a)) = n a,
   linearity, and A[0] = sum(a).
 """
@@ -110,6 +114,67 @@ def test_msm_2_20_properties(h2, curve):
         p1 = O.to_affine(cid, bases.msm(ones))
         pc = O.to_affine(cid, bases.msm(consts))
         assert np.array_equal(O.to_affine(cid, O.scalar_mul(cid, L(fs, c), p1)), pc)
+    finally:
+        bases.release()
+
+
+def test_msm_2_24_known_answer(h2):
+    import torch
+    curve = "pallas"
+    cid = O.CURVE_IDS[curve]
+    fid = O.CURVE_SCALAR_FIELD[cid]
+    fs = R.CURVES[curve].scalar
+    n = 1 << 24
+    s = 0x2B7E151628AED2A6ABF7158809CF4F3C762E7160F38B4DA56A784D9045190CFE % fs.p
+    g = srs(h2, curve, s, n)
+    gen = g[0].cpu().numpy().view(np.uint64)                    # [s^0]G = the generator
+    bases = h2.Bases.from_device(curve, g.data_ptr(), n)
+    try:
+        dense = O.synth_scalars(fid, 0x48324D5300000500, n).reshape(n, 4)
+        sparse = np.zeros((n, 4), dtype=np.uint64)              # 64 dense rows on top, 6 at the bottom
+        sparse[:64] = dense[:64]
+        sparse[n - 6:] = dense[n - 6:]
+        cols = torch.from_numpy(np.stack([dense, sparse]).view(np.int64)).cuda()
+        out = torch.zeros((2, 12), dtype=torch.int64, device="cuda")
+        bases.msm_device(cols.data_ptr(), n, 2, out.data_ptr())
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        for j, col in enumerate((dense, sparse)):
+            k = O.eval_polynomial(fid, col, L(fs, s))
+            want = O.to_affine(cid, O.scalar_mul(cid, k, gen))
+            assert np.array_equal(O.to_affine(cid, res[j]), want), "column %d" % j
+    finally:
+        bases.release()
+
+
+def test_msm_column_groups_equal_one_launch(h2, monkeypatch):
+    import torch
+    curve = "bn254"
+    cid = O.CURVE_IDS[curve]
+    fid = O.CURVE_SCALAR_FIELD[cid]
+    n, m = 1 << 10, 5
+    b = O.synth_bases(cid, 0x48324D53000006B5, n).reshape(n, 8)
+    bases = h2.Bases(curve, b)
+    try:
+        cols = np.stack([O.synth_scalars(fid, 0x48324D5300000600 + j, n).reshape(n, 4) for j in range(m)])
+        whole = bases.msm_batch(list(cols))
+        windows = bases.plan()["windows"]
+        monkeypatch.setenv("H2_MSM_MAX_ENTRIES", str(2 * windows * n))      # two columns per launch: groups 2 + 2 + 1
+        grouped = bases.msm_batch(list(cols))
+        dev = torch.from_numpy(cols.view(np.int64)).cuda()
+        out = torch.zeros((m, 12), dtype=torch.int64, device="cuda")
+        bases.msm_device(dev.data_ptr(), n, m, out.data_ptr())
+        torch.cuda.synchronize()
+        monkeypatch.setenv("H2_MSM_MAX_ENTRIES", str(windows * n - 1))      # not even one column fits: rejected
+        with pytest.raises(h2.H2Error) as err:
+            bases.msm_batch(list(cols))
+        assert err.value.status == -1                                       # H2_EINVAL
+        monkeypatch.delenv("H2_MSM_MAX_ENTRIES")
+        assert np.array_equal(whole, grouped)
+        jac = out.cpu().numpy().view(np.uint64)
+        for j in range(m):
+            assert np.array_equal(O.to_affine(cid, jac[j]), whole[j])
+            assert np.array_equal(whole[j], O.to_affine(cid, O.best_multiexp(cid, cols[j], b)))
     finally:
         bases.release()
 

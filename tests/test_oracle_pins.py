@@ -158,6 +158,18 @@ def test_synthetic_generators_agree_between_pyref_and_c():
         assert [f.from_mont(O.limbs_to_int(got[4 * i:4 * i + 4])) for i in range(8)] == want
 
 
+def test_eval_polynomial_matches_big_int_horner():
+    for name, fid in O.FIELD_IDS.items():
+        f = R.FIELDS[name]
+        rng = R.SplitMix64(77)
+        co = [R.synth_scalar(rng, f.p) for _ in range(33)]
+        x = R.synth_scalar(rng, f.p)
+        want = sum(c * pow(x, i, f.p) for i, c in enumerate(co)) % f.p
+        got = O.eval_polynomial(fid, np.array([f.limbs(c) for c in co], dtype=np.uint64), np.array(f.limbs(x), dtype=np.uint64))
+        assert f.from_mont(O.limbs_to_int(got)) == want
+        assert not O.eval_polynomial(fid, np.zeros((0, 4), dtype=np.uint64), np.array(f.limbs(x), dtype=np.uint64)).any()
+
+
 def test_oracle_msm_pasta_self_consistency():
     """Pallas/Vesta curve results are 'parity unpinned' in the reference: self-consistency only."""
     for name in ("pallas", "vesta"):
