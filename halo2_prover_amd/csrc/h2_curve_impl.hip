@@ -129,6 +129,7 @@ __global__ void selftest_field_kernel(int op, const U128* a_, const U128* b_, U1
     case 4: r = fe_to_mont(a); break;
     case 5: r = fe_from_mont(a); break;
     case 7: r = fe_mul_cios(a, b); break;
+    case 8: r = fe_mul_lat(a, b); break;
     default: r = fe_neg(a); break;
   }
   fe_store<FP>(out + 2 * (size_t)i, r);

@@ -57,19 +57,19 @@ __device__ __forceinline__ Xyzz<CV> xyzz_double_quad(const Xyzz<CV>& p) {
   const F u = fe_dbl(p.y);
   // level 1: v = u^2 (lane 0), xx = x^2 (lane 1); lanes 2, 3 repeat lane 1's product
   const F o1 = quad_select(q, u, p.x, p.x, p.x);
-  const F m1 = fe_mul(o1, o1);
+  const F m1 = fe_mul_lat(o1, o1);
   const F v = quad_bcast<0>(m1), xx = quad_bcast<1>(m1);
   const F m = fe_add(fe_dbl(xx), xx);
   // level 2: w = u v, s = x v, mm = m^2, zz3 = v zz
   const F a2 = quad_select(q, u, p.x, m, v);
   const F b2 = quad_select(q, v, v, m, p.zz);
-  const F m2 = fe_mul(a2, b2);
+  const F m2 = fe_mul_lat(a2, b2);
   const F w = quad_bcast<0>(m2), s = quad_bcast<1>(m2), mm = quad_bcast<2>(m2), zz3 = quad_bcast<3>(m2);
   const F x3 = fe_sub(fe_sub(mm, s), s);
   // level 3: m (s - x3), w y, zzz3 = w zzz
   const F a3 = quad_select(q, m, w, w, w);
   const F b3 = quad_select(q, fe_sub(s, x3), p.y, p.zzz, p.zzz);
-  const F m3 = fe_mul(a3, b3);
+  const F m3 = fe_mul_lat(a3, b3);
   const F y3 = fe_sub(quad_bcast<0>(m3), quad_bcast<1>(m3));
   return Xyzz<CV>{x3, y3, zz3, quad_bcast<2>(m3)};
 }
@@ -82,7 +82,7 @@ __device__ __forceinline__ Xyzz<CV> xyzz_add_quad(const Xyzz<CV>& a, const Xyzz<
   if (b.is_identity()) return a;
   const uint32_t q = threadIdx.x & 3;
   // level 1
-  const F m1 = fe_mul(quad_select(q, a.x, b.x, a.y, b.y), quad_select(q, b.zz, a.zz, b.zzz, a.zzz));
+  const F m1 = fe_mul_lat(quad_select(q, a.x, b.x, a.y, b.y), quad_select(q, b.zz, a.zz, b.zzz, a.zzz));
   const F u1 = quad_bcast<0>(m1), u2 = quad_bcast<1>(m1), s1 = quad_bcast<2>(m1), s2 = quad_bcast<3>(m1);
   const F p = fe_sub(u2, u1), r = fe_sub(s2, s1);
   if (p.is_zero()) {
@@ -90,15 +90,15 @@ __device__ __forceinline__ Xyzz<CV> xyzz_add_quad(const Xyzz<CV>& a, const Xyzz<
     return Xyzz<CV>::identity();
   }
   // level 2: pp, rr, zz12, zzz12
-  const F m2 = fe_mul(quad_select(q, p, r, a.zz, a.zzz), quad_select(q, p, r, b.zz, b.zzz));
+  const F m2 = fe_mul_lat(quad_select(q, p, r, a.zz, a.zzz), quad_select(q, p, r, b.zz, b.zzz));
   const F pp = quad_bcast<0>(m2), rr = quad_bcast<1>(m2);
   // level 3: ppp = p pp, qq = u1 pp, zz3 = zz12 pp (lane 2 keeps its own m2), lane 3 carries zzz12 forward (times 1
   // would cost a product: it simply repeats lane 2's work and keeps m2 in a register)
-  const F m3 = fe_mul(quad_select(q, p, u1, m2, m2), pp);
+  const F m3 = fe_mul_lat(quad_select(q, p, u1, m2, m2), pp);
   const F ppp = quad_bcast<0>(m3), qq = quad_bcast<1>(m3), zz3 = quad_bcast<2>(m3);
   const F x3 = fe_sub(fe_sub(fe_sub(rr, ppp), qq), qq);
   // level 4: r (qq - x3), s1 ppp, -, zzz3 = zzz12 ppp (lane 3's m2 is zzz12)
-  const F m4 = fe_mul(quad_select(q, r, s1, s1, m2), quad_select(q, fe_sub(qq, x3), ppp, ppp, ppp));
+  const F m4 = fe_mul_lat(quad_select(q, r, s1, s1, m2), quad_select(q, fe_sub(qq, x3), ppp, ppp, ppp));
   const F y3 = fe_sub(quad_bcast<0>(m4), quad_bcast<1>(m4));
   return Xyzz<CV>{x3, y3, zz3, quad_bcast<3>(m4)};
 }

@@ -21,7 +21,8 @@ int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t 
  * by double-and-add.  p, q: affine (8 limbs); out: affine (8 limbs), identity = zeros. */
 int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]);
 /* The same field ops through the DEVICE instantiation (gfx950 Comba multiplier): n element pairs, host
- * pointers, one kernel launch.  op 7 = the portable CIOS product compiled for the device (cross-check). */
+ * pointers, one kernel launch.  op 7 = the portable CIOS product compiled for the device (cross-check),
+ * op 8 = the row-ordered latency form used by the 4-lanes-per-point kernels. */
 int h2_selftest_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* host run of the signed-digit window decomposition used by the MSM digits kernel.
  * scalar: Montgomery limbs; geometry chosen as for `n_for_geometry` registered bases.
