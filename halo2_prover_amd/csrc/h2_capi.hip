@@ -17,6 +17,7 @@
 #include "h2_curve_ops.hpp"
 #include "h2_msm.hpp"
 #include "h2_ntt.hpp"
+#include "h2_poly.hpp"
 
 using namespace h2;
 
@@ -46,6 +47,7 @@ struct Context {
   size_t ws_bytes = 0;
   void* stage = nullptr;    // device staging for host-pointer entry points
   size_t stage_bytes = 0;
+  void* div_ws = nullptr;   // chunk values of h2_poly_divide_linear_device (2 * 1024 elements)
   std::map<uint64_t, BasesEntry> bases;
   uint64_t next_handle = 1;
   std::vector<TwiddleEntry> twiddles;
@@ -287,7 +289,8 @@ int h2_shutdown(void) {
   g_ctx.twiddles.clear();
   if (g_ctx.ws) (void)hipFree(g_ctx.ws);
   if (g_ctx.stage) (void)hipFree(g_ctx.stage);
-  g_ctx.ws = g_ctx.stage = nullptr;
+  if (g_ctx.div_ws) (void)hipFree(g_ctx.div_ws);
+  g_ctx.ws = g_ctx.stage = g_ctx.div_ws = nullptr;
   g_ctx.ws_bytes = g_ctx.stage_bytes = 0;
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
@@ -545,6 +548,35 @@ int h2_poly_inverse_device(h2_curve_t curve, void* d_a, size_t n, void* stream_)
   if (n == 0) return H2_OK;
   hipError_t e = ops_of((int)curve)->poly_inverse(d_a, n, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_inverse_kernel");
+  return H2_OK;
+}
+
+int h2_poly_divide_linear_device(h2_curve_t curve, const void* d_a, size_t n, const uint64_t z[4], void* d_q,
+                                 void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !d_q || !z || d_a == d_q) return H2_EINVAL;
+  if (n == 0) return H2_OK;
+  if (!g_ctx.div_ws) H2_TRY(hipMalloc(&g_ctx.div_ws, (size_t)2 * DIV_MAX_CHUNKS * 32));
+  hipError_t e = ops_of((int)curve)->poly_divide_linear(d_a, n, z, d_q, g_ctx.div_ws,
+                                                        stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "poly_divide kernels");
+  return H2_OK;
+}
+
+int h2_chacha20_scalars_device(h2_curve_t curve, const uint8_t seed[32], uint64_t first_block, size_t n, void* d_out,
+                               void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !seed || !d_out) return H2_EINVAL;
+  if (n == 0) return H2_OK;
+  uint32_t key[8];
+  for (int i = 0; i < 8; i++)
+    key[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) |
+             ((uint32_t)seed[4 * i + 3] << 24);
+  hipError_t e = ops_of((int)curve)->chacha20_scalars(d_out, n, first_block, key,
+                                                      stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "chacha20_scalars_kernel");
   return H2_OK;
 }
 

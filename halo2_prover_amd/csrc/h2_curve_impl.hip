@@ -89,6 +89,18 @@ hipError_t poly_inverse(void* d_a, size_t total, hipStream_t s) {
   hipLaunchKernelGGL(poly_inverse_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a, total);
   return hipGetLastError();
 }
+hipError_t poly_divide_linear(const void* d_a, size_t n, const uint64_t z[4], void* d_q, void* d_ws, hipStream_t s) {
+  Fe<FS> zv;
+  memcpy(zv.v, z, 32);
+  return poly_divide_linear_launch<FS>((const U128*)d_a, n, zv, (U128*)d_q, (U128*)d_ws, s);
+}
+hipError_t chacha20_scalars(void* d_out, size_t n, uint64_t first_block, const uint32_t key[8], hipStream_t s) {
+  ChaChaKey k;
+  memcpy(k.w, key, 32);
+  hipLaunchKernelGGL(chacha20_scalars_kernel<FS>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (U128*)d_out, n,
+                     first_block, k);
+  return hipGetLastError();
+}
 hipError_t poly_pointwise(void* d_a, const void* d_b, size_t total, int op, hipStream_t s) {
   hipLaunchKernelGGL(poly_pointwise_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a,
                      (const U128*)d_b, total, op);
@@ -190,7 +202,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers, fixed_base_mul,
                       to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
-                      poly_pointwise, poly_inverse, selftest_field, selftest_curve,
+                      poly_pointwise, poly_inverse, poly_divide_linear, chacha20_scalars, selftest_field, selftest_curve,
                       selftest_field_device, selftest_digits};
 
 }  // namespace

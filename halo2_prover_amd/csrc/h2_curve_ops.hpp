@@ -35,6 +35,10 @@ struct CurveOps {
   hipError_t (*poly_mul_periodic)(void* d_a, size_t total, const void* d_t, size_t period, hipStream_t s);
   hipError_t (*poly_pointwise)(void* d_a, const void* d_b, size_t total, int op, hipStream_t s);
   hipError_t (*poly_inverse)(void* d_a, size_t total, hipStream_t s);
+  // d_q = (d_a - d_a(z)) / (X - z); d_ws: 2 * 1024 elements of scratch
+  hipError_t (*poly_divide_linear)(const void* d_a, size_t n, const uint64_t z[4], void* d_q, void* d_ws, hipStream_t s);
+  // d_out[i] = Scalar::random of ChaCha20 block first_block + i (key = the 32 seed bytes as 8 little-endian words)
+  hipError_t (*chacha20_scalars)(void* d_out, size_t n, uint64_t first_block, const uint32_t key[8], hipStream_t s);
   // host self-test hooks (host instantiation of the same templates)
   int (*selftest_field)(int which /* 0 = base field, 1 = scalar field */, int op, const uint64_t* a,
                         const uint64_t* b, uint64_t* out);

@@ -59,15 +59,6 @@ def _horner(coeffs, x):
     return acc
 
 
-def _kate_division(a, z):
-    q = [0] * (len(a) - 1)
-    acc = 0
-    for i in range(len(a) - 1, 0, -1):
-        acc = (a[i] + acc * z) % P
-        q[i - 1] = acc
-    return q
-
-
 def _batch_inverse(vals):
     prefix, acc = [], 1
     for v in vals:
@@ -92,38 +83,6 @@ class OsRng:
         for i in range(8):
             v |= int.from_bytes(self.fill(8), "little") << (64 * i)
         return v % P
-
-
-def _chacha20_field_elements(seed32, count):
-    """`count` values of Fr::random(ChaCha20Rng::from_seed(seed)): rand_chacha 0.3.1 (20 rounds, 64-bit block
-    counter from 0, stream 0); one 64-byte block per element, read as a 512-bit little-endian integer mod r.
-    All blocks are generated at once with numpy."""
-    key = np.frombuffer(seed32, dtype="<u4").astype(np.uint32)
-    s = np.zeros((16, count), dtype=np.uint32)
-    s[0], s[1], s[2], s[3] = 0x61707865, 0x3320646E, 0x79622D32, 0x6B206574
-    for i in range(8):
-        s[4 + i] = key[i]
-    ctr = np.arange(count, dtype=np.uint64)
-    s[12] = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    s[13] = (ctr >> np.uint64(32)).astype(np.uint32)
-    init = s.copy()
-
-    def rotl(v, c):
-        return (v << np.uint32(c)) | (v >> np.uint32(32 - c))
-
-    def quarter(a, b, c, d):
-        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16)
-        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12)
-        s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8)
-        s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7)
-
-    with np.errstate(over="ignore"):
-        for _ in range(10):
-            quarter(0, 4, 8, 12); quarter(1, 5, 9, 13); quarter(2, 6, 10, 14); quarter(3, 7, 11, 15)
-            quarter(0, 5, 10, 15); quarter(1, 6, 11, 12); quarter(2, 7, 8, 13); quarter(3, 4, 9, 14)
-        s += init
-    blocks = np.ascontiguousarray(s.T).astype("<u4").tobytes()      # element i = 64 consecutive bytes
-    return [int.from_bytes(blocks[64 * i:64 * i + 64], "little") % P for i in range(count)]
 
 
 class _Transcript:
@@ -698,6 +657,22 @@ class _Dev:
                                                self.dom._stream()), "h2_poly_scale_device")
         return t
 
+    def divide_linear(self, col, z):
+        """(col - col(z)) / (X - z) as a new column: kate_division on the device"""
+        col = col.contiguous()
+        q = self.torch.empty_like(col)
+        zm = _limbs_of([z])
+        _lib.check(self.L.h2_poly_divide_linear_device(self.curve, self._p(col), col.shape[0], zm.ctypes.data,
+                                                       self._p(q), self.dom._stream()), "h2_poly_divide_linear_device")
+        return q
+
+    def random_scalars(self, seed32, count):
+        """`count` draws of Fr::random(ChaCha20Rng::from_seed(seed32)) as a device column"""
+        t = self.torch.empty((count, 4), dtype=self.torch.int64, device="cuda")
+        _lib.check(self.L.h2_chacha20_scalars_device(self.curve, seed32, 0, count, self._p(t), self.dom._stream()),
+                   "h2_chacha20_scalars_device")
+        return t
+
     def inverse_(self, t):
         _lib.check(self.L.h2_poly_inverse_device(self.curve, self._p(t), t.numel() // 4, self.dom._stream()),
                    "h2_poly_inverse_device")
@@ -896,12 +871,12 @@ def _interpolate(points, values):
 
 
 def _divide_linear_device(dev, col, points):
-    """col / prod (X - p) for a device column known to vanish at the points: the synthetic division is a serial
-    recurrence, so it runs on the host (one column down, one column up)"""
-    q = dev.to_ints(col)
+    """col / prod (X - p) for a device column known to vanish at the points: one kate_division per point, on the
+    device (the quotient keeps the column's length, its top coefficients are zero)"""
+    q = col
     for pt in points:
-        q = _kate_division(q, pt)
-    return dev.from_ints(q + [0] * (col.shape[0] - len(q)))
+        q = dev.divide_linear(q, pt)
+    return q
 
 
 def _shplonk_open(tr, dev, n, queries, evals, trace):
@@ -1037,7 +1012,7 @@ def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
         tr.write_point(pt)
 
     # random polynomial of the vanishing argument (one thread chunk: one seed, n sequential draws)
-    random_poly = dev.from_ints(_chacha20_field_elements(rng.fill(32), n))
+    random_poly = dev.random_scalars(rng.fill(32), n)
     rng.fr_random()
     tr.write_point(dev.commit(random_poly.unsqueeze(0), lagrange=False)[0])
 

@@ -113,6 +113,15 @@ int h2_poly_mul_periodic_device(h2_curve_t curve, void* d_a, size_t n, size_t m,
 int h2_poly_inverse_device(h2_curve_t curve, void* d_a, size_t n, void* stream);
 /* a[i] = a[i] op b[i] over n elements; op 0 = add, 1 = sub, 2 = mul */
 int h2_poly_pointwise_device(h2_curve_t curve, int op, void* d_a, const void* d_b, size_t n, void* stream);
+/* q = (a - a(z)) / (X - z) over n coefficients, q[n-1] = 0: halo2_proofs src/arithmetic.rs `kate_division(a, z)`
+ * (the witness polynomials of the GWC / SHPLONK openings).  d_q must not alias d_a. */
+int h2_poly_divide_linear_device(h2_curve_t curve, const void* d_a, size_t n, const uint64_t z[4], void* d_q,
+                                 void* stream);
+/* out[i] = Scalar::random(rng) number first_block + i of rng = ChaCha20Rng::from_seed(seed), Montgomery limbs:
+ * the coefficients of the vanishing argument's random_poly (halo2_proofs src/plonk/vanishing/prover.rs
+ * `Argument::commit`).  Each draw consumes one 64-byte ChaCha20 block. */
+int h2_chacha20_scalars_device(h2_curve_t curve, const uint8_t seed[32], uint64_t first_block, size_t n, void* d_out,
+                               void* stream);
 
 /* ---- introspection used by bench.py's roofline (no effect on results) --------------------
  * Names the kernels launched by the last h2_msm* / h2_ntt* call and their geometry. */

@@ -93,3 +93,87 @@ def test_quotient_of_a_product_k16(h2):
     assert (av * bv - rv - hv * (pow(x, n, p) - 1)) % p == 0
     # top half of h is zero: deg(a*b) < 2n so deg(h) < n
     assert not h_c[n:].any().item()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "pallas"])
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 1000, 1 << 12, (1 << 14) + 5])
+def test_divide_linear_matches_kate_division(h2, curve, n):
+    """h2_poly_divide_linear_device against the oracle's synthetic division (halo2_ref.pdiv_linear): every chunking
+    case (one short chunk, a ragged last chunk, 1024 chunks) and q[n-1] = 0."""
+    import ctypes
+    import torch
+    f = R.CURVES[curve].scalar
+    p = f.p
+    rng = R.SplitMix64(31 * n + len(curve))
+    a = [R.synth_scalar(rng, p) for _ in range(n)]
+    z = R.synth_scalar(rng, p)
+    want, acc = [0] * n, 0
+    for i in range(n - 1, 0, -1):            # pdiv_linear, written for this field (halo2_ref fixes BN254's Fr)
+        acc = (a[i] + acc * z) % p
+        want[i - 1] = acc
+    if curve == "bn254":
+        import halo2_ref as H
+        assert H.pdiv_linear(a, z) == want[:n - 1]
+    d_a = torch.from_numpy(np.array([f.limbs(v) for v in a], dtype=np.uint64).view(np.int64)).cuda()
+    d_q = torch.full_like(d_a, -1)
+    zm = np.array(f.limbs(z), dtype=np.uint64)
+    L = h2.load()
+    st = L.h2_poly_divide_linear_device(h2.CURVES[curve], ctypes.c_void_p(d_a.data_ptr()), n, zm.ctypes.data,
+                                        ctypes.c_void_p(d_q.data_ptr()), None)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert to_ints(f, d_q) == want
+    # in place is refused (the recurrence reads what a neighbour chunk writes)
+    assert L.h2_poly_divide_linear_device(h2.CURVES[curve], ctypes.c_void_p(d_a.data_ptr()), n, zm.ctypes.data,
+                                          ctypes.c_void_p(d_a.data_ptr()), None) == -1
+
+
+def test_divide_linear_full_size_property(h2):
+    """n = 2^19 (512 rows per chunk): q (X - z) + a(z) = a, checked at a random point."""
+    import ctypes
+    import torch
+    curve, n = "pallas", 1 << 19
+    cid = O.CURVE_IDS[curve]
+    fid = O.CURVE_SCALAR_FIELD[cid]
+    f = R.CURVES[curve].scalar
+    a = O.synth_scalars(fid, 0x48324D5300000700, n).reshape(n, 4)
+    z, x = 0x1234567890ABCDEF1122334455667788 % f.p, 0x0FEDCBA987654321AABBCCDDEEFF0011 % f.p
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    d_q = torch.empty_like(d_a)
+    zm = np.array(f.limbs(z), dtype=np.uint64)
+    assert h2.load().h2_poly_divide_linear_device(cid, ctypes.c_void_p(d_a.data_ptr()), n, zm.ctypes.data,
+                                                  ctypes.c_void_p(d_q.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    q = d_q.cpu().numpy().view(np.uint64)
+    ev = lambda col, pt: f.from_mont(O.limbs_to_int(O.eval_polynomial(fid, col, np.array(f.limbs(pt), dtype=np.uint64))))
+    assert (ev(q, x) * (x - z) + ev(a, z)) % f.p == ev(a, x)
+    assert not q[n - 1].any()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "pallas", "vesta"])
+def test_chacha20_scalars_match_the_oracle_rng(h2, curve):
+    """h2_chacha20_scalars_device against halo2_ref.ChaCha20Rng (rand_chacha's block function + the 512-bit
+    reduction of ff's `random`).  The oracle's generator is itself pinned by the recorded proof hashes: the blinding
+    polynomial it produces is committed to and opened in every proof (tests/test_proof_pins.py)."""
+    import ctypes
+    import torch
+    import halo2_ref as H
+    f = R.CURVES[curve].scalar
+    seed = bytes((7 * i + 3) & 0xFF for i in range(32))
+    n = 300
+    rng = H.ChaCha20Rng(seed)
+    want = []
+    for _ in range(n):
+        v = 0
+        for i in range(16):
+            v |= rng.next_u32() << (32 * i)
+        want.append(v % f.p)
+    out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    L = h2.load()
+    assert L.h2_chacha20_scalars_device(h2.CURVES[curve], seed, 0, n, ctypes.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert to_ints(f, out) == want
+    # a later starting block continues the same stream
+    assert L.h2_chacha20_scalars_device(h2.CURVES[curve], seed, 100, 50, ctypes.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert to_ints(f, out[:50]) == want[100:150]
