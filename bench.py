@@ -251,13 +251,17 @@ def main():
 
     # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read
     # in-process); the committed summary is used when it was taken on this workload, else null
-    traffic = None
+    traffic = ntt_traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if args.workload == "poseidon" and args.curve == "pallas" and k == 16:
             traffic = pmc["dominant_kernel"]["traffic_bytes_per_launch"]
+            # the step's three batched transforms are two ntt_pass_kernel launches each
+            ntt_traffic = 6 * next(v for name, v in pmc["kernels"].items() if "ntt_pass_kernel" in name)["traffic_bytes_per_launch"]
     except Exception:
-        traffic = None
+        traffic = ntt_traffic = None
+    if roofline_ntt:
+        roofline_ntt["traffic"] = ntt_traffic          # bytes per step, like algorithmic_bytes_per_step
     roofline = None
     if prof.launches:
         achieved = prof.algorithmic_bytes / (prof.kernel_ms * 1e-3) / 1e9
@@ -278,7 +282,7 @@ def main():
     if rank == 0:
         workload = {"poseidon": "poseidon_k%d_proof_shape: 16 MSM(2^%d) in phases m=4,2,1,5,4 + 7 iNTT(2^%d) + "
                                 "7 NTT(2^%d) + 1 iNTT(2^%d)" % (k, k, k, k + ext, k + ext),
-                    "msm": "msm(2^%d) x %d columns" % (k, args.msm_cols), "ntt": "ntt(2^%d)" % k}[args.workload]
+                    "msm": "msm(2^%d) x %d columns" % (k, args.msm_cols), "ntt": "ntt(2^%d) x %d columns" % (k, args.ntt_cols)}[args.workload]
         out = {
             "metric": "MSM+NTT field-ops/s", "value": value, "unit": "field-ops/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -337,20 +341,28 @@ def proof_generation(k):
     params = prover.generate_params(k, rng)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    circuit = prover.PoseidonCircuit([1, 2])
-    pk = prover.generate_keys(params, circuit)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    proof = prover.generate_proof_with_instance(params, pk, circuit, [circuit.output()], rng)
-    torch.cuda.synchronize()
-    t3 = time.perf_counter()
-    digest = hashlib.sha256(proof).hexdigest()
+    after_setup = rng.counter
+    runs = []
+    for _ in range(2):                       # first run: cold (kernel modules load, arenas grow); second: steady state
+        rng.counter = after_setup            # the same draws again, so both runs must give the recorded proof
+        ta = time.perf_counter()
+        circuit = prover.PoseidonCircuit([1, 2])
+        pk = prover.generate_keys(params, circuit)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        proof = prover.generate_proof_with_instance(params, pk, circuit, [circuit.output()], rng)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        runs.append((tb - ta, tc - tb, hashlib.sha256(proof).hexdigest(), len(proof)))
+    (kg0, cp0, d0, _), (kg, cp, digest, nbytes) = runs
+    same = (digest == REFERENCE_PROOF_SHA256[k] and d0 == digest) if k in REFERENCE_PROOF_SHA256 else None
     return {"circuit": "poseidon (bn254, KZG/GWC)", "k": k, "setup_ms": round((t1 - t0) * 1e3, 1),
-            "keygen_ms": round((t2 - t1) * 1e3, 1), "create_proof_ms": round((t3 - t2) * 1e3, 1),
-            "proof_gen_ms": round((t3 - t1) * 1e3, 1), "proof_bytes": len(proof), "proof_sha256": digest,
-            "bit_identical_to_reference": (digest == REFERENCE_PROOF_SHA256[k]) if k in REFERENCE_PROOF_SHA256 else None,
-            "note": "proof_gen_ms = keygen + create_proof as wasm_generate_proof does (wall clock, host side "
-                    "included: witness synthesis, transcript, grand-product recurrence, GWC divisions)"}
+            "keygen_ms": round(kg * 1e3, 1), "create_proof_ms": round(cp * 1e3, 1),
+            "proof_gen_ms": round((kg + cp) * 1e3, 1), "proof_gen_first_call_ms": round((kg0 + cp0) * 1e3, 1),
+            "proof_bytes": nbytes, "proof_sha256": digest, "bit_identical_to_reference": same,
+            "note": "proof_gen_ms = keygen + create_proof as wasm_generate_proof does, wall clock with the host side "
+                    "included (witness synthesis, transcript, grand-product recurrence), second call in the process; "
+                    "proof_gen_first_call_ms is the first call (kernel modules loading, arenas growing)"}
 
 
 def cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R):

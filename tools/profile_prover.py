@@ -19,8 +19,11 @@ rng = _RecordedStream()
 params = prover.generate_params(k, rng)
 circuit = prover.PoseidonCircuit([1, 2])
 t0 = time.perf_counter()
+prk = cProfile.Profile()
+prk.enable()
 pk = prover.generate_keys(params, circuit)
 torch.cuda.synchronize()
+prk.disable()
 t1 = time.perf_counter()
 pr = cProfile.Profile()
 pr.enable()
@@ -30,3 +33,5 @@ pr.disable()
 t2 = time.perf_counter()
 print("keygen %.3f s, create_proof %.3f s, sha256 %s" % (t1 - t0, t2 - t1, hashlib.sha256(proof).hexdigest()[:16]))
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+print("---- keygen ----")
+pstats.Stats(prk).sort_stats("cumulative").print_stats(28)
