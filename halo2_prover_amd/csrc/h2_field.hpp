@@ -260,7 +260,9 @@ __device__ __forceinline__ Fe<FP> fe_mul_comba(const Fe<FP>& a, const Fe<FP>& b)
 // share the SIMD).  Here every column K of a*b + m*p has its OWN accumulator: the 64 limb products are issued row
 // by row, so consecutive multiply-adds hit different columns and are independent; only the reduction walks the
 // columns in order (carry in, m[K], carry out), scattering m[K] * p[J] into the columns above it as soon as m[K]
-// exists.  Same instruction count, ~45 more live registers -- which a lone wave has to spare.
+// exists.  ~6 % more VALU instructions but a fifth of the s_nops, ~45 more live registers -- which a lone wave has to
+// spare.  Measured in the throughput-bound kernels instead of fe_mul_comba it is SLOWER (accumulate kernel 0.437 ->
+// 0.460 ms, NTT passes 0.63 -> 0.70 ms per step): there other waves fill the s_nop slots and only the VALU count matters.
 namespace detail {
 // Blocks of independent multiply-adds: the carry of each v_mad_u64_u32 goes to its OWN scalar register pair and is
 // folded into the column's carry count only after the whole block has been issued, so the in-order pipeline never
