@@ -50,7 +50,10 @@ struct MsmGeom {
 inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
   uint32_t lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
-  int c = (int)lg - 4;
+  // measured on the Poseidon proof shape (bench.py --k 12 / 14 / 16 / 18) and on single 2^20 columns: wider windows
+  // save additions in the accumulate kernel (W = ceil(256 / c)) but every bucket costs ~16 point operations in the
+  // tail, so the best width is log2 n - 3 up to 2^16 and log2 n - 4 above
+  int c = (int)lg - (lg <= 16 ? 3 : 4);
   if (c < 6) c = 6;
   if (c > (int)MSM_MAX_C) c = (int)MSM_MAX_C;
   MsmGeom g{};
@@ -578,7 +581,6 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   while ((1u << lq) < span && lq < 4) lq++;
   while (lq > 0 && (ws.K << lq) > 40960) lq--;
   uint32_t lg = lq + 2;
-  if (const char* ov = getenv("H2_FIXUP_LOG_G")) lg = (uint32_t)atoi(ov);   // tuning aid
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
   size_t tile = (n * m + 1023) / 1024;
