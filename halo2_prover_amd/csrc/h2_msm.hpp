@@ -273,8 +273,7 @@ msm_chunk_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T
   for (uint32_t j = (s + T - 1) / T; (uint64_t)j * T < e; j++) chunk_first[j] = (uint32_t)key;
 }
 
-// Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device; T is a multiple of 4 and
-// the refs are read as 16-byte vectors.  A run (maximal stretch of one key inside the chunk) that holds the key's
+// Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device.  A run (maximal stretch of one key inside the chunk) that holds the key's
 // whole list goes to bucket_sum[key]; a cut-off first run goes to head[t], a cut-off last run to tail[t].
 template <class CV>
 __global__ void __launch_bounds__(256)
@@ -290,27 +289,19 @@ msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ so
   uint32_t next = offsets[key + 1];          // first entry of the following list
   bool first = true;
   Xyzz<CV> a = Xyzz<CV>::identity();
-  for (uint32_t e4 = lo; e4 < hi; e4 += 4) {
-    const U128 quad = *reinterpret_cast<const U128*>(sorted_ref + e4);   // 16-byte aligned: lo and e4 are multiples of 4
-    const uint32_t refs[4] = {quad.x, quad.y, quad.z, quad.w};
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-      const uint32_t e = e4 + k;
-      if (e < hi) {
-        if (e >= next) {
-          // the run of `key` ended inside the chunk
-          if (first && offsets[key] != lo) xyzz_store<CV>(head + 8 * (size_t)t, a);
-          else xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
-          first = false;
-          a = Xyzz<CV>::identity();
-          do {                                  // skip empty lists
-            key++;
-            next = offsets[key + 1];
-          } while (e >= next);
-        }
-        a = xyzz_add_affine(a, msm_fetch<CV>(table, refs[k]));
-      }
+  for (uint32_t e = lo; e < hi; e++) {
+    if (e >= next) {
+      // the run of `key` ended inside the chunk
+      if (first && offsets[key] != lo) xyzz_store<CV>(head + 8 * (size_t)t, a);
+      else xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
+      first = false;
+      a = Xyzz<CV>::identity();
+      do {                                  // skip empty lists
+        key++;
+        next = offsets[key + 1];
+      } while (e >= next);
     }
+    a = xyzz_add_affine(a, msm_fetch<CV>(table, sorted_ref[e]));
   }
   const bool ends_here = next == hi;
   const bool starts_here = !first || offsets[key] == lo;
@@ -566,11 +557,21 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.K = m * g.B;
   ws.E = m * g.W * n;
   ws.nblk = (ws.K + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  // enough threads to fill 256 CUs x 4 SIMDs x 4 waves, at least 8 and at most 64 additions each
-  uint64_t T = (ws.E + 262143) / 262144;
-  if (T < 8) T = 8;
-  if (T > 64) T = 64;
-  T = (T + 3) & ~(uint64_t)3;                     // the accumulate kernel reads refs four at a time
+  // Additions per thread.  The accumulate kernel is one resident round of VALU-bound waves, so it lasts as long as
+  // the SIMDs that hold the most waves: pick T so that the launch is a WHOLE number w of waves per SIMD (1024 SIMDs
+  // x 64 lanes = 65536 threads per unit of w) and w * T is smallest; fewer, longer chunks also mean fewer pieces for
+  // the fix-up.  Big inputs take T = 64 and several rounds, where the rounding no longer matters.
+  uint64_t T = 64;
+  {
+    uint64_t best = ~0ull;
+    for (uint64_t w = 4; w >= 2; w--) {
+      uint64_t t = (ws.E + w * 65536 - 1) / (w * 65536);
+      if (t < 8) t = 8;
+      if (t > 64) continue;
+      const uint64_t cost = w * t * (w == 2 ? 21 : 20);      // two waves per SIMD hide a little less latency
+      if (cost < best) { best = cost; T = t; }
+    }
+  }
   ws.T = (uint32_t)T;
   ws.nchunks = (ws.E + T - 1) / T;
   // pieces per key ~ list length / T + 1
@@ -597,7 +598,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
   ws.off_cursor = o; o = h2_align256(o + ws.K * 4);
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
-  ws.off_ref = o; o = h2_align256(o + ws.E * 4 + 16);             // + one vector of slack for the last 16-byte read
+  ws.off_ref = o; o = h2_align256(o + ws.E * 4);
   ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
   ws.off_misc = o; o = h2_align256(o + 64);
   ws.off_bsum = o; o = h2_align256(o + ws.K * 128);
