@@ -262,17 +262,6 @@ __device__ __forceinline__ Affine<CV> msm_fetch(const U128* __restrict__ table, 
   return p;
 }
 
-// chunk_first[t] = the key that owns sorted entry t*T (the first entry of chunk t): one thread per key writes the
-// chunks that START inside its list.  Each chunk start lies in exactly one non-empty list, so every slot below
-// ceil(E / T) gets exactly one writer.
-static __global__ void __launch_bounds__(256)
-msm_chunk_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t* __restrict__ chunk_first) {
-  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= K) return;
-  const uint32_t s = offsets[key], e = offsets[key + 1];
-  for (uint32_t j = (s + T - 1) / T; (uint64_t)j * T < e; j++) chunk_first[j] = (uint32_t)key;
-}
-
 // Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device.  A run (maximal stretch of one key inside the chunk) that holds the key's
 // whole list goes to bucket_sum[key]; a cut-off first run goes to head[t], a cut-off last run to tail[t].
 template <class CV>
@@ -338,13 +327,16 @@ __device__ __forceinline__ Xyzz<CV> msm_piece(const U128* __restrict__ head, con
 // thousands of entries into one bucket.  The chunk kernel does not care -- every thread still adds T entries -- but
 // the bucket then has thousands of pieces.  One thread per key: keys with more than MSM_HOT_SPAN pieces reserve
 // ceil(span / MSM_HOT_SEG) slots and emit one task per slot.
+// The same pass gives every chunk its first key: chunk_first[j] = key for the chunks that START inside the key's
+// list (each chunk start lies in exactly one non-empty list, so every slot below ceil(E / T) gets one writer).
 static __global__ void __launch_bounds__(256)
-msm_hot_tasks_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t* __restrict__ hot_slot,
-                     uint32_t* __restrict__ tasks /* 2 words each: key, segment */, uint32_t* task_count,
-                     uint32_t max_tasks) {
+msm_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t* __restrict__ chunk_first,
+                uint32_t* __restrict__ hot_slot, uint32_t* __restrict__ tasks /* 2 words each: key, segment */,
+                uint32_t* task_count, uint32_t max_tasks) {
   const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (key >= K) return;
   const uint32_t s = offsets[key], e = offsets[key + 1];
+  for (uint32_t j = (s + T - 1) / T; (uint64_t)j * T < e; j++) chunk_first[j] = (uint32_t)key;
   uint32_t slot = MSM_NOT_HOT;
   if (e > s) {
     const uint32_t span = (e - 1) / T - s / T + 1;
@@ -594,13 +586,13 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.lvl1 = (g.B + MSM_TREE_SEG - 1) / MSM_TREE_SEG;
   size_t o = 0;
   ws.off_digits = o; o = h2_align256(o + ws.E * 4);
+  ws.off_misc = o; o += 256;                                      // misc[0] = hot task counter; zeroed with counts
   ws.off_counts = o; o = h2_align256(o + ws.K * 4);
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
   ws.off_cursor = o; o = h2_align256(o + ws.K * 4);
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
   ws.off_ref = o; o = h2_align256(o + ws.E * 4);
   ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
-  ws.off_misc = o; o = h2_align256(o + 64);
   ws.off_bsum = o; o = h2_align256(o + ws.K * 128);
   ws.off_head = o; o = h2_align256(o + ws.nchunks * 128);
   ws.off_tail = o; o = h2_align256(o + ws.nchunks * 128);
@@ -644,9 +636,10 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   uint32_t* hot_tasks = (uint32_t*)(ws_base + ws.off_hot_tasks);
   U128* hot_part = (U128*)(ws_base + ws.off_hot_part);
   hipError_t e;
-  if ((e = hipMemsetAsync(counts, 0, ws.K * 4, stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(bsum, 0, ws.K * 128, stream)) != hipSuccess) return e;   // empty buckets = identity
-  if ((e = hipMemsetAsync(misc, 0, 64, stream)) != hipSuccess) return e;           // misc[0] = hot task counter
+  // one memset: misc (256 B) sits directly before counts.  Nothing else needs clearing: every slot of bucket_sum /
+  // head / tail that a later kernel reads has been written by the accumulate kernel (the fix-up decides from
+  // `offsets` which slots exist).
+  if ((e = hipMemsetAsync(misc, 0, 256 + ws.K * 4, stream)) != hipSuccess) return e;
   const size_t lds = (size_t)g.B * 4;
   if (lds > 48 * 1024) {
     if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -657,20 +650,19 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
   hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(256), lds, stream, d_scalars, digits,
                      counts, (uint32_t)n, n, ws.tile, g);
+  // (a single-block scan for small K was measured: 21 us against 14 us for these three launches)
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      cursor, ws.K);
   hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(256), lds, stream, digits, cursor, sref,
                      (uint32_t)n, n_bases, ws.tile, g);
-  hipLaunchKernelGGL(msm_chunk_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K,
-                     ws.T, chunk_first);
+  hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
+                     chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
   if (ev_start) (void)hipEventRecord(ev_start, stream);
   hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
                      sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-  hipLaunchKernelGGL(msm_hot_tasks_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K,
-                     ws.T, hot_slot, hot_tasks, misc, ws.max_tasks);
   hipLaunchKernelGGL(msm_hot_reduce_kernel<CV>, dim3(1024), dim3(64), 0, stream, offsets, ws.T, hot_slot, hot_tasks,
                      misc, ws.max_tasks, head, tail, hot_part);
   const size_t fix_threads = ws.K << ws.log_g;
