@@ -278,7 +278,13 @@ msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ so
   uint32_t next = offsets[key + 1];          // first entry of the following list
   bool first = true;
   Xyzz<CV> a = Xyzz<CV>::identity();
+  U128 quad = U128{0, 0, 0, 0};
   for (uint32_t e = lo; e < hi; e++) {
+    // refs are fetched as aligned 16-byte vectors whatever T is (the first one may start below lo, the last one may
+    // reach up to 12 bytes past E: the array is allocated with that slack)
+    if (e == lo || (e & 3u) == 0) quad = *reinterpret_cast<const U128*>(sorted_ref + (e & ~3u));
+    const uint32_t sel = e & 3u;
+    const uint32_t ref = sel == 0 ? quad.x : sel == 1 ? quad.y : sel == 2 ? quad.z : quad.w;
     if (e >= next) {
       // the run of `key` ended inside the chunk
       if (first && offsets[key] != lo) xyzz_store<CV>(head + 8 * (size_t)t, a);
@@ -290,7 +296,7 @@ msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ so
         next = offsets[key + 1];
       } while (e >= next);
     }
-    a = xyzz_add_affine(a, msm_fetch<CV>(table, sorted_ref[e]));
+    a = xyzz_add_affine(a, msm_fetch<CV>(table, ref));
   }
   const bool ends_here = next == hi;
   const bool starts_here = !first || offsets[key] == lo;
@@ -591,7 +597,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
   ws.off_cursor = o; o = h2_align256(o + ws.K * 4);
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
-  ws.off_ref = o; o = h2_align256(o + ws.E * 4);
+  ws.off_ref = o; o = h2_align256(o + ws.E * 4 + 16);             // + slack for the last 16-byte read
   ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
   ws.off_bsum = o; o = h2_align256(o + ws.K * 128);
   ws.off_head = o; o = h2_align256(o + ws.nchunks * 128);

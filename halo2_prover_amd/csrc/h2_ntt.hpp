@@ -7,8 +7,8 @@
 // Contract kept: in place, natural order in and out, A[k] = sum_j a[j] w^(jk), unscaled.
 //
 // Structure (MI355X-first, not the reference's recursion): n = R1 * R2 * R3 with every radix
-// <= 2^10.  Each pass stages a tile of R x C elements in LDS (C consecutive "columns" so that
-// every HBM access is a run of C*32 contiguous bytes), runs the log2(R) butterfly stages out
+// <= 2^10.  Each pass stages a tile of R x C elements in LDS (C consecutive "columns", so every HBM access is a
+// run of C*32 contiguous bytes; C = 4, or 2 for R >= 512 so that the tile stays <= 72 KB and two blocks share a CU), runs the log2(R) butterfly stages out
 // of LDS with the R/2 twiddles of that radix also held in LDS, applies the inter-pass
 // twiddle w^(outer*i*k) and writes the tile back.  The last pass writes the digit-reversed
 // position directly, so no bit-reversal sweep over HBM is needed.  Per pass the algorithmic
@@ -223,9 +223,9 @@ struct NttPlan {
   uint32_t tiles[3];
 };
 
-constexpr uint32_t NTT_MAX_LOG_R = 10;  // R <= 1024: tile R*4 elements = 128 KiB + 16 KiB twiddles
+constexpr uint32_t NTT_MAX_LOG_R = 10;  // R <= 1024: tile R*2 elements = 64 KiB + 16 KiB twiddles
 
-inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R, uint32_t want_log_c = 2) {
+inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R) {
   NttPlan pl{};
   uint32_t np = log_n == 0 ? 1 : (log_n + max_log_r - 1) / max_log_r;
   if (np > 3) np = 3;  // callers reject log_n > 30
@@ -246,7 +246,10 @@ inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R,
     P.is_final = (p == np - 1);
     P.log_r1 = np >= 2 ? radix[0] : 0;
     P.log_r2 = np == 3 ? radix[1] : 0;
-    uint32_t lc = want_log_c;
+    // tile columns: keep the tile at <= 72 KB of LDS so that at least two blocks share a CU (one computes while the
+    // other waits at a barrier): 2 columns for R >= 512, 4 below (measured: R = 1024 x 4 columns, one block per CU,
+    // is 13 % slower on the 2^19 transforms; R = 256 x 2 columns is 5-30 % slower than x 4 on the 2^16 ones)
+    uint32_t lc = radix[p] >= 9 ? 1 : 2;
     if (P.is_final) {
       if (lc > P.log_r1) lc = P.log_r1;
     } else {
