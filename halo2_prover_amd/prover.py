@@ -32,6 +32,7 @@ import numpy as np
 
 from . import lib as _lib
 from .api import ParamsKZG
+from . import sharded as _sharded
 from .domain import EvaluationDomain
 
 P = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001       # bn256::Fr modulus
@@ -698,11 +699,22 @@ class _Dev:
     def commit(self, cols, lagrange):
         """m device columns (m, n, 4) -> m affine points (canonical ints); the MSM result never leaves the device
         until it is 96 bytes per column"""
-        cols = cols.contiguous()
+        import torch.distributed as dist
         m, n = cols.shape[0], cols.shape[1]
         bases = self.params._gl if lagrange else self.params._g
-        out = self.torch.zeros((m, 12), dtype=self.torch.int64, device="cuda")
-        bases.msm_device(cols.data_ptr(), n, m, out.data_ptr(), self.dom._stream().value or 0)
+        sharded = (dist.is_available() and dist.is_initialized() and m > 1 and
+                   (dist.get_world_size() > 1 or _sharded.FORCE_GATHER))
+        if sharded:
+            # one process per GPU: column j of the phase is committed by rank j mod world, then ONE all-gather of the
+            # 96-byte results gives every rank the whole vector for its transcript (SURVEY.md section 8(e))
+            mine = _sharded.shard_columns(m, dist.get_rank(), dist.get_world_size())
+            cols = cols[mine]
+        cols = cols.contiguous()
+        out = self.torch.zeros((cols.shape[0], 12), dtype=self.torch.int64, device="cuda")
+        if cols.shape[0]:
+            bases.msm_device(cols.data_ptr(), n, cols.shape[0], out.data_ptr(), self.dom._stream().value or 0)
+        if sharded:
+            out = _sharded.gather_columns(out, m)
         self.torch.cuda.synchronize()
         raw = out.cpu().numpy().tobytes()
         pts = []

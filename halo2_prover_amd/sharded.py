@@ -9,10 +9,36 @@ There is no other collective on this path.
 """
 import numpy as np
 
+# tests set this to run the gather even in a one-rank group (the RCCL code path on a one-GPU box)
+FORCE_GATHER = False
+
 
 def shard_columns(m, rank, world):
     """indices of the columns rank `rank` commits to"""
     return list(range(rank, m, world))
+
+
+def gather_columns(local, m, group=None):
+    """`local`: this rank's results as a (len(shard_columns(m, rank, world)), w) int64 tensor, rows in shard order.
+    Returns the (m, w) tensor in column order on every rank -- the one collective of a commit phase
+    (`all_gather_into_tensor`; every rank sends ceil(m / world) rows, short shards padded with zeros).
+    RCCL gathers device tensors in place; any other backend (gloo in the tests) goes through host memory."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    slots = (m + world - 1) // world
+    w = local.shape[1]
+    on_device = dist.get_backend(group) == "nccl"
+    dev = local.device if on_device else torch.device("cpu")
+    send = torch.zeros((slots, w), dtype=torch.int64, device=dev)
+    send[:local.shape[0]] = local.to(dev)
+    recv = torch.empty((world * slots, w), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    # rank r's row i is column r + i * world
+    cols = torch.arange(m)
+    order = (cols % world) * slots + cols // world
+    return recv[order.to(dev)].to(local.device)
 
 
 def commit_columns(bases, columns, group=None, msm_batch=None):
@@ -34,20 +60,9 @@ def commit_columns(bases, columns, group=None, msm_batch=None):
     rank = dist.get_rank(group)
     mine = shard_columns(m, rank, world)
     local = np.asarray(msm_batch([columns[j] for j in mine]), dtype=np.uint64).reshape(len(mine), 8)
-    slots = (m + world - 1) // world                     # every rank contributes the same number of rows
-    send = np.zeros((slots, 8), dtype=np.uint64)
-    send[:len(mine)] = local
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    t_send = torch.from_numpy(send.view(np.int64)).to(dev)
-    t_recv = torch.empty((world * slots, 8), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(t_recv, t_send, group=group)   # the one collective
-    recv = t_recv.cpu().numpy().view(np.uint64).reshape(world, slots, 8)
-    out = np.zeros((m, 8), dtype=np.uint64)
-    for r in range(world):
-        for i, j in enumerate(shard_columns(m, r, world)):
-            out[j] = recv[r, i]
-    return out
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    out = gather_columns(torch.from_numpy(local.view(np.int64)).to(dev), m, group)
+    return out.cpu().numpy().view(np.uint64).reshape(m, 8)
 
 
 def split_msm_by_range(n, rank, world):
