@@ -365,7 +365,7 @@ def proof_generation(k, world=1):
             "proof_gen_ms": round((kg + cp) * 1e3, 1), "proof_gen_first_call_ms": round((kg0 + cp0) * 1e3, 1),
             "proof_bytes": nbytes, "proof_sha256": digest, "bit_identical_to_reference": same,
             "note": "proof_gen_ms = keygen + create_proof as wasm_generate_proof does, wall clock with the host side "
-                    "included (witness synthesis, transcript, grand-product recurrence), second call in the process; "
+                    "included (witness synthesis, transcript), second call in the process; "
                     "proof_gen_first_call_ms is the first call (kernel modules loading, arenas growing)"}
 
 

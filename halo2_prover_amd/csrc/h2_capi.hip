@@ -564,6 +564,18 @@ int h2_poly_divide_linear_device(h2_curve_t curve, const void* d_a, size_t n, co
   return H2_OK;
 }
 
+int h2_poly_prefix_product_device(h2_curve_t curve, const void* d_a, size_t n, void* d_out, void* stream_) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !d_a || !d_out) return H2_EINVAL;
+  if (n == 0) return H2_OK;
+  if (!g_ctx.div_ws) H2_TRY(hipMalloc(&g_ctx.div_ws, (size_t)2 * DIV_MAX_CHUNKS * 32));
+  hipError_t e = ops_of((int)curve)->poly_prefix_product(d_a, n, d_out, g_ctx.div_ws,
+                                                         stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "poly_prefix kernels");
+  return H2_OK;
+}
+
 int h2_chacha20_scalars_device(h2_curve_t curve, const uint8_t seed[32], uint64_t first_block, size_t n, void* d_out,
                                void* stream_) {
   std::lock_guard<std::mutex> lk(g_mu);

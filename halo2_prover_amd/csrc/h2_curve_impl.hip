@@ -94,6 +94,9 @@ hipError_t poly_divide_linear(const void* d_a, size_t n, const uint64_t z[4], vo
   memcpy(zv.v, z, 32);
   return poly_divide_linear_launch<FS>((const U128*)d_a, n, zv, (U128*)d_q, (U128*)d_ws, s);
 }
+hipError_t poly_prefix_product(const void* d_a, size_t n, void* d_out, void* d_ws, hipStream_t s) {
+  return poly_prefix_product_launch<FS>((const U128*)d_a, n, (U128*)d_out, (U128*)d_ws, s);
+}
 hipError_t chacha20_scalars(void* d_out, size_t n, uint64_t first_block, const uint32_t key[8], hipStream_t s) {
   ChaChaKey k;
   memcpy(k.w, key, 32);
@@ -202,7 +205,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers, fixed_base_mul,
                       to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
-                      poly_pointwise, poly_inverse, poly_divide_linear, chacha20_scalars, selftest_field, selftest_curve,
+                      poly_pointwise, poly_inverse, poly_divide_linear, poly_prefix_product, chacha20_scalars, selftest_field, selftest_curve,
                       selftest_field_device, selftest_digits};
 
 }  // namespace

@@ -37,6 +37,8 @@ struct CurveOps {
   hipError_t (*poly_inverse)(void* d_a, size_t total, hipStream_t s);
   // d_q = (d_a - d_a(z)) / (X - z); d_ws: 2 * 1024 elements of scratch
   hipError_t (*poly_divide_linear)(const void* d_a, size_t n, const uint64_t z[4], void* d_q, void* d_ws, hipStream_t s);
+  // d_out[i] = prod_{j < i} d_a[j] (d_out[0] = 1; may alias d_a); d_ws as above
+  hipError_t (*poly_prefix_product)(const void* d_a, size_t n, void* d_out, void* d_ws, hipStream_t s);
   // d_out[i] = Scalar::random of ChaCha20 block first_block + i (key = the 32 seed bytes as 8 little-endian words)
   hipError_t (*chacha20_scalars)(void* d_out, size_t n, uint64_t first_block, const uint32_t key[8], hipStream_t s);
   // host self-test hooks (host instantiation of the same templates)

@@ -140,6 +140,67 @@ inline hipError_t poly_divide_linear_launch(const U128* a, size_t n, const Fe<FP
   return hipGetLastError();
 }
 
+// ---- exclusive prefix product: out[i] = prod_{j < i} a[j], out[0] = 1 ------------------------------------------
+// The permutation argument's grand product (halo2_proofs @6b43b6b src/plonk/permutation/prover.rs `Argument::commit`:
+// z[0] = last_z, z[i+1] = z[i] * numerator[i] / denominator[i]) is this scan of the per-row ratios, times last_z.
+// Same three launches as the division: chunk products, log-step scan of the chunk products in one block, then the
+// recurrence inside every chunk.  May run in place (a thread reads a[i] before it writes out[i]).
+template <class FP>
+__global__ void __launch_bounds__(64)
+poly_prefix_chunk_kernel(const U128* __restrict__ a, size_t n, uint32_t L, uint32_t C, U128* __restrict__ H) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const size_t lo = (size_t)c * L, hi = min(n, lo + L);
+  Fe<FP> acc = Fe<FP>::one();
+  for (size_t i = lo; i < hi; i++) acc = fe_mul(acc, fe_load<FP>(a + 2 * i));
+  fe_store<FP>(H + 2 * c, acc);
+}
+
+// G[c] = prod_{d < c} H[d]
+template <class FP>
+__global__ void __launch_bounds__(1024)
+poly_prefix_scan_kernel(const U128* __restrict__ H, uint32_t C, U128* __restrict__ G) {
+  __shared__ U128 lds[2 * DIV_MAX_CHUNKS];
+  const uint32_t c = threadIdx.x;
+  Fe<FP> y = c < C ? fe_load<FP>(H + 2 * c) : Fe<FP>::one();
+  for (uint32_t s = 1; s < C; s <<= 1) {
+    fe_store<FP>(lds + 2 * c, y);
+    __syncthreads();
+    if (c >= s) y = fe_mul(y, fe_load<FP>(lds + 2 * (c - s)));
+    __syncthreads();
+  }
+  fe_store<FP>(lds + 2 * c, y);
+  __syncthreads();
+  if (c < C) fe_store<FP>(G + 2 * c, c > 0 ? fe_load<FP>(lds + 2 * (c - 1)) : Fe<FP>::one());
+}
+
+template <class FP>
+__global__ void __launch_bounds__(64)
+poly_prefix_apply_kernel(const U128* a, size_t n, uint32_t L, uint32_t C, const U128* __restrict__ G, U128* out) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const size_t lo = (size_t)c * L, hi = min(n, lo + L);
+  Fe<FP> cur = fe_load<FP>(G + 2 * c);
+  for (size_t i = lo; i < hi; i++) {
+    const Fe<FP> x = fe_load<FP>(a + 2 * i);
+    fe_store<FP>(out + 2 * i, cur);
+    cur = fe_mul(cur, x);
+  }
+}
+
+template <class FP>
+inline hipError_t poly_prefix_product_launch(const U128* a, size_t n, U128* out, U128* d_ws, hipStream_t stream) {
+  uint32_t L = (uint32_t)((n + DIV_MAX_CHUNKS - 1) / DIV_MAX_CHUNKS);
+  if (L < 16) L = 16;
+  const uint32_t C = (uint32_t)((n + L - 1) / L);
+  U128* H = d_ws;
+  U128* G = d_ws + 2 * DIV_MAX_CHUNKS;
+  hipLaunchKernelGGL(poly_prefix_chunk_kernel<FP>, dim3((C + 63) / 64), dim3(64), 0, stream, a, n, L, C, H);
+  hipLaunchKernelGGL(poly_prefix_scan_kernel<FP>, dim3(1), dim3(DIV_MAX_CHUNKS), 0, stream, H, C, G);
+  hipLaunchKernelGGL(poly_prefix_apply_kernel<FP>, dim3((C + 63) / 64), dim3(64), 0, stream, a, n, L, C, G, out);
+  return hipGetLastError();
+}
+
 // ---- the blinding polynomial's coefficients ------------------------------------------------------------------
 // out[i] = Scalar::random(ChaCha20Rng::from_seed(seed)) number first + i (halo2_proofs @6b43b6b
 // src/plonk/vanishing/prover.rs `Argument::commit`: random_poly from a ChaCha20Rng seeded off the prover's rng;

@@ -49,6 +49,7 @@ SYMBOLS = {
     "h2_poly_mul_periodic_device": (_I, [_I, _P, _Z, _Z, _P, _Z, _P]),
     "h2_poly_pointwise_device": (_I, [_I, _I, _P, _P, _Z, _P]),
     "h2_poly_divide_linear_device": (_I, [_I, _P, _Z, _P, _P, _P]),
+    "h2_poly_prefix_product_device": (_I, [_I, _P, _Z, _P, _P]),
     "h2_chacha20_scalars_device": (_I, [_I, _P, _U64, _Z, _P, _P]),
     "h2_poly_inverse_device": (_I, [_I, _P, _Z, _P]),
     "h2_msm_plan": (_I, [_U64, ctypes.POINTER(MsmPlan)]),

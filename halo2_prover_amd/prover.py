@@ -16,10 +16,10 @@ What runs where:
   * the quotient h(X): coset NTTs of every column, the gate / permutation expressions with the pointwise kernels,
     divide_by_vanishing_poly, inverse coset NTT                          (GPU, EvaluationDomain)
   * setup: g = [s^i]G and g_lagrange = [L_i(s)]G                         (GPU, h2_srs_generate / h2_fixed_base_mul)
-  * evaluations at x (powers-multiply + folding adds), the v-power combinations of the openings and the
-    grand-product ratios (per-element inverse kernel)                    (GPU, pointwise kernels on resident columns)
-  * transcript hashing, witness synthesis, the permutation union-find, the grand-product running product and
-    the synthetic divisions of the openings                              (host Python, big integers)
+  * evaluations at x (powers-multiply + folding adds), the v-power combinations of the openings, the
+    grand-product ratios (per-element inverse kernel) and their running product (prefix-product scan), the
+    openings' synthetic divisions, the blinding polynomial's ChaCha20 draws  (GPU, kernels on resident columns)
+  * transcript hashing, witness synthesis, the permutation union-find    (host Python, big integers)
 There is no CPU fallback for the GPU parts.  Columns stay resident in HBM as 4 x u64 Montgomery limbs; the
 conversion from / to canonical integers runs on the device.
 """
@@ -667,6 +667,14 @@ class _Dev:
                                                        self._p(q), self.dom._stream()), "h2_poly_divide_linear_device")
         return q
 
+    def prefix_product(self, col):
+        """the column prod_{j < i} col[j] (1 in row 0)"""
+        col = col.contiguous()
+        out = self.torch.empty_like(col)
+        _lib.check(self.L.h2_poly_prefix_product_device(self.curve, self._p(col), col.shape[0], self._p(out),
+                                                        self.dom._stream()), "h2_poly_prefix_product_device")
+        return out
+
     def random_scalars(self, seed32, count):
         """`count` draws of Fr::random(ChaCha20Rng::from_seed(seed32)) as a device column"""
         t = self.torch.empty((count, 4), dtype=self.torch.int64, device="cuda")
@@ -994,8 +1002,7 @@ def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
     theta, beta, gamma = tr.squeeze_challenge(), tr.squeeze_challenge(), tr.squeeze_challenge()
     trace.update(theta=theta, beta=beta, gamma=gamma)
 
-    # permutation grand products, d - 2 columns per set: the per-row ratios on the device, the running product
-    # (a serial recurrence) on the host
+    # permutation grand products, d - 2 columns per set: per-row ratios and their running product on the device
     values_of = {"advice": advice_values, "fixed": pk.fixed_values, "instance": instance_values}
     pcols = circuit.permutation_columns
     sets = [list(range(s, min(s + d - 2, len(pcols)))) for s in range(0, len(pcols), d - 2)]
@@ -1010,15 +1017,14 @@ def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
             td = dev.add_(dev.scale(pk.sigma_values[j], beta), vg)
             num = tn if num is None else dev.mul_(num, tn)
             den = td if den is None else dev.mul_(den, td)
-        ratio = dev.to_ints(dev.mul_(num, dev.inverse_(den)))
-        z = [last_z] * n
-        for i in range(n - bf - 1):
-            z[i + 1] = z[i] * ratio[i] % P
-        for row in range(n - bf, n):
-            z[row] = rng.fr_random()
-        last_z = z[n - bf - 1]
+        # z[i] = last_z * prod_{j < i} ratio[j] on the usable rows: a prefix product on the device; only the 32 bytes of
+        # its last usable row come back (the next set starts from there)
+        pref = dev.prefix_product(dev.mul_(num, dev.inverse_(den)))
+        z = dev.scale(pref, last_z) if last_z != 1 else pref
+        z[n - bf:] = dev.from_ints([rng.fr_random() for _ in range(bf)])
+        last_z = last_z * dev.to_ints(pref[n - bf - 1:n - bf])[0] % P
         rng.fr_random()
-        z_cols.append(dev.from_ints(z))
+        z_cols.append(z)
     z_values = torch.stack(z_cols)
     for pt in dev.commit(z_values, lagrange=True):
         tr.write_point(pt)

@@ -117,6 +117,10 @@ int h2_poly_pointwise_device(h2_curve_t curve, int op, void* d_a, const void* d_
  * (the witness polynomials of the GWC / SHPLONK openings).  d_q must not alias d_a. */
 int h2_poly_divide_linear_device(h2_curve_t curve, const void* d_a, size_t n, const uint64_t z[4], void* d_q,
                                  void* stream);
+/* out[i] = prod_{j < i} a[j], out[0] = 1 (n elements; d_out may alias d_a): the running product of the permutation
+ * argument, z[i+1] = z[i] * ratio[i] (halo2_proofs src/plonk/permutation/prover.rs `Argument::commit`; SURVEY.md
+ * App. A.4) -- the caller multiplies by last_z and writes the blinding rows. */
+int h2_poly_prefix_product_device(h2_curve_t curve, const void* d_a, size_t n, void* d_out, void* stream);
 /* out[i] = Scalar::random(rng) number first_block + i of rng = ChaCha20Rng::from_seed(seed), Montgomery limbs:
  * the coefficients of the vanishing argument's random_poly (halo2_proofs src/plonk/vanishing/prover.rs
  * `Argument::commit`).  Each draw consumes one 64-byte ChaCha20 block. */

@@ -177,3 +177,33 @@ def test_chacha20_scalars_match_the_oracle_rng(h2, curve):
     assert L.h2_chacha20_scalars_device(h2.CURVES[curve], seed, 100, 50, ctypes.c_void_p(out.data_ptr()), None) == 0
     torch.cuda.synchronize()
     assert to_ints(f, out[:50]) == want[100:150]
+
+
+@pytest.mark.parametrize("curve", ["bn254", "vesta"])
+@pytest.mark.parametrize("n", [1, 2, 16, 17, 1000, (1 << 14) + 3, 1 << 17])
+def test_prefix_product_matches_the_running_product(h2, curve, n):
+    """h2_poly_prefix_product_device against z[i+1] = z[i] * a[i], z[0] = 1 in big integers (zeros included: every
+    later row becomes 0), out of place and in place."""
+    import ctypes
+    import torch
+    f = R.CURVES[curve].scalar
+    p = f.p
+    fid = O.CURVE_SCALAR_FIELD[O.CURVE_IDS[curve]]
+    a_l = O.synth_scalars(fid, 0x48324D5300000800 + n, n).reshape(n, 4).copy()
+    if n > 1000:
+        a_l[n - 5] = 0                                   # a vanishing ratio late in the column
+    a = [f.from_mont(O.limbs_to_int(r)) for r in a_l]
+    want, acc = [], 1
+    for v in a:
+        want.append(acc)
+        acc = acc * v % p
+    d_a = torch.from_numpy(a_l.view(np.int64)).cuda()
+    d_o = torch.full_like(d_a, -1)
+    L = h2.load()
+    cid = h2.CURVES[curve]
+    assert L.h2_poly_prefix_product_device(cid, ctypes.c_void_p(d_a.data_ptr()), n, ctypes.c_void_p(d_o.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert to_ints(f, d_o) == want
+    assert L.h2_poly_prefix_product_device(cid, ctypes.c_void_p(d_a.data_ptr()), n, ctypes.c_void_p(d_a.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert to_ints(f, d_a) == want
