@@ -339,10 +339,29 @@ static __global__ void __launch_bounds__(256)
 msm_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t* __restrict__ chunk_first,
                 uint32_t* __restrict__ hot_slot, uint32_t* __restrict__ tasks /* 2 words each: key, segment */,
                 uint32_t* task_count, uint32_t max_tasks) {
+  // long lists (degenerate columns: tens of thousands of chunks under one key) are filled by the whole block
+  __shared__ uint32_t long_key[256];
+  __shared__ uint32_t n_long;
+  if (threadIdx.x == 0) n_long = 0;
+  __syncthreads();
   const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= K) return;
-  const uint32_t s = offsets[key], e = offsets[key + 1];
-  for (uint32_t j = (s + T - 1) / T; (uint64_t)j * T < e; j++) chunk_first[j] = (uint32_t)key;
+  const bool live = key < K;
+  const uint32_t s = live ? offsets[key] : 0, e = live ? offsets[key + 1] : 0;
+  if (live) {
+    const uint32_t j0 = (s + T - 1) / T;
+    const uint64_t j1 = ((uint64_t)e + T - 1) / T;             // chunks j0 .. j1-1 start inside [s, e)
+    if (j1 > (uint64_t)j0 + 64) long_key[atomicAdd(&n_long, 1u)] = (uint32_t)key;
+    else
+      for (uint32_t j = j0; j < j1; j++) chunk_first[j] = (uint32_t)key;
+  }
+  __syncthreads();
+  for (uint32_t q = 0; q < n_long; q++) {
+    const uint32_t lk = long_key[q];
+    const uint32_t ls = offsets[lk], le = offsets[lk + 1];
+    const uint64_t j1 = ((uint64_t)le + T - 1) / T;
+    for (uint64_t j = (uint64_t)(ls + T - 1) / T + threadIdx.x; j < j1; j += blockDim.x) chunk_first[j] = lk;
+  }
+  if (!live) return;
   uint32_t slot = MSM_NOT_HOT;
   if (e > s) {
     const uint32_t span = (e - 1) / T - s / T + 1;
