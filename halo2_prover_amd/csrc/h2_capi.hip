@@ -656,6 +656,24 @@ extern "C" int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_
   return ops->selftest_digits(scalar, n_for_geometry, out, cap);
 }
 // n element pairs through the DEVICE instantiation (one kernel launch); host pointers in and out
+extern "C" int h2_selftest_curve_op_device(int curve, int op, const uint64_t* p, const uint64_t* q, uint64_t* out,
+                                           size_t n) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return H2_ENOTINIT;
+  const CurveOps* ops = ops_of(curve);
+  if (!ops || !p || !q || !out || n == 0 || n > (1u << 20)) return H2_EINVAL;
+  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, 3 * n * 64);
+  if (rc != H2_OK) return rc;
+  char* d = (char*)g_ctx.stage;
+  H2_TRY(hipMemcpyAsync(d, p, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
+  H2_TRY(hipMemcpyAsync(d + n * 64, q, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
+  hipError_t e = ops->selftest_curve_device(op, d, d + n * 64, d + 2 * n * 64, (uint32_t)n, g_ctx.stream);
+  if (e != hipSuccess) return dev_fail(e, "selftest_curve_kernel");
+  H2_TRY(hipMemcpyAsync(out, d + 2 * n * 64, n * 64, hipMemcpyDeviceToHost, g_ctx.stream));
+  H2_TRY(hipStreamSynchronize(g_ctx.stream));
+  return H2_OK;
+}
+
 extern "C" int h2_selftest_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                                            size_t n) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -46,12 +46,12 @@ hipError_t fixed_base_mul(void* d_out_affine, const void* d_scalars, uint32_t n,
   return hipGetLastError();
 }
 hipError_t to_jacobian(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
-  hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const U128*)d_xyzz,
+  hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const uint32_t*)d_xyzz,
                      (U128*)d_out, m);
   return hipGetLastError();
 }
 hipError_t to_affine(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
-  hipLaunchKernelGGL(msm_to_affine_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const U128*)d_xyzz,
+  hipLaunchKernelGGL(msm_to_affine_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const uint32_t*)d_xyzz,
                      (U128*)d_out, m);
   return hipGetLastError();
 }
@@ -116,6 +116,15 @@ int selftest_field_t(int op, const uint64_t* a_, const uint64_t* b_, uint64_t* o
   memcpy(a.v, a_, 32);
   memcpy(b.v, b_, 32);
   switch (op) {
+    case 9: r = fe29_to_api(fe29_mul(fe29_from_api(a), fe29_from_api(b))); break;            // working-form product
+    case 10: r = fe29_to_api(fe29_add(fe29_from_api(a), fe29_from_api(b))); break;
+    case 11: r = fe29_to_api(fe29_sub(fe29_from_api(a), fe29_from_api(b))); break;
+    case 12: {   // a long lazy chain: ((a - b)^2 - a b - 2 b) stays within the working form's bounds
+      const Fe29<FP> x = fe29_from_api(a), y = fe29_from_api(b);
+      const Fe29<FP> d = fe29_sub(x, y);
+      r = fe29_to_api(fe29_norm(fe29_sub(fe29_sub(fe29_sub(fe29_sqr(d), fe29_mul(x, y)), y), y)));
+      break;
+    }
     case 0: r = fe_add(a, b); break;
     case 1: r = fe_sub(a, b); break;
     case 2: r = fe_mul(a, b); break;
@@ -145,6 +154,7 @@ __global__ void selftest_field_kernel(int op, const U128* a_, const U128* b_, U1
     case 5: r = fe_from_mont(a); break;
     case 7: r = fe_mul_cios(a, b); break;
     case 8: r = fe_mul_lat(a, b); break;
+    case 9: r = fe29_to_api(fe29_mul(fe29_from_api(a), fe29_from_api(b))); break;
     default: r = fe_neg(a); break;
   }
   fe_store<FP>(out + 2 * (size_t)i, r);
@@ -157,6 +167,45 @@ hipError_t selftest_field_device(int which, int op, const void* d_a, const void*
   else
     hipLaunchKernelGGL(selftest_field_kernel<FS>, dim3((n + 63) / 64), dim3(64), 0, s, op, (const U128*)d_a,
                        (const U128*)d_b, (U128*)d_out, n);
+  return hipGetLastError();
+}
+// n pairs (p, q) of affine points in the API form, four lanes per pair; out: affine, API form
+__global__ void __launch_bounds__(64)
+selftest_curve_kernel(int op, const U128* p_, const U128* q_, U128* out, uint32_t n) {
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (i >= n) return;
+  const Affine<CV> pa = affine_load<CV>(p_ + 4 * (size_t)i), qa = affine_load<CV>(q_ + 4 * (size_t)i);
+  const Affine29<CV> p9{fe29_from_api(pa.x), fe29_from_api(pa.y)}, q9{fe29_from_api(qa.x), fe29_from_api(qa.y)};
+  const Xyzz29<CV> P = xyzz29_from_affine(p9), Q = xyzz29_from_affine(q9);
+  Xyzz29<CV> r;
+  switch (op) {
+    case 0: r = xyzz29_add_quad(P, Q); break;
+    case 1: r = xyzz29_double_quad(P); break;
+    case 2: r = xyzz29_add(P, Q); break;
+    case 3: r = xyzz29_double(P); break;
+    case 4: r = xyzz29_add_quad(xyzz29_double_quad(P), Q); break;
+    default: {
+      const uint32_t k = qa.x.v[0];
+      r = Xyzz29<CV>::identity();
+      if (k) {
+        const int top = 31 - __clz(k);
+        r = P;
+        for (int bit = top - 1; bit >= 0; bit--) {
+          r = xyzz29_double_quad(r);
+          if ((k >> bit) & 1) r = xyzz29_add_quad(r, P);
+        }
+      }
+    }
+  }
+  const Affine<CV> a = xyzz_to_affine(xyzz29_to_api(r));
+  if ((threadIdx.x & 3) == 0) {
+    fe_store<FB>(out + 4 * (size_t)i, a.x);
+    fe_store<FB>(out + 4 * (size_t)i + 2, a.y);
+  }
+}
+hipError_t selftest_curve_device(int op, const void* d_p, const void* d_q, void* d_out, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(selftest_curve_kernel, dim3((4 * n + 63) / 64), dim3(64), 0, s, op, (const U128*)d_p,
+                     (const U128*)d_q, (U128*)d_out, n);
   return hipGetLastError();
 }
 int selftest_curve(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out) {
@@ -176,6 +225,24 @@ int selftest_curve(int op, const uint64_t* p_, const uint64_t* q_, uint64_t* out
         r = xyzz_double(r);
         if ((k >> bit) & 1) r = xyzz_add(r, base);
       }
+      break;
+    }
+    case 10: case 11: case 12: case 13: {          // the same four operations on the working representation
+      const Affine29<CV> p9{fe29_from_api(p.x), fe29_from_api(p.y)}, q9{fe29_from_api(q.x), fe29_from_api(q.y)};
+      Xyzz29<CV> r9;
+      if (op == 10) r9 = xyzz29_add_affine(xyzz29_from_affine(p9), q9);
+      else if (op == 11) r9 = xyzz29_double_affine(p9);
+      else if (op == 12) r9 = xyzz29_add(xyzz29_add_affine(xyzz29_from_affine(p9), q9), xyzz29_from_affine(q9));
+      else {
+        const uint32_t k = (uint32_t)q_[0];
+        r9 = Xyzz29<CV>::identity();
+        const Xyzz29<CV> base = xyzz29_from_affine(p9);
+        for (int bit = 31; bit >= 0; bit--) {
+          r9 = xyzz29_double(r9);
+          if ((k >> bit) & 1) r9 = xyzz29_add(r9, base);
+        }
+      }
+      r = xyzz29_to_api(r9);
       break;
     }
     default: return -1;
@@ -206,7 +273,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers, fixed_base_mul,
                       to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
                       poly_pointwise, poly_inverse, poly_divide_linear, poly_prefix_product, chacha20_scalars, selftest_field, selftest_curve,
-                      selftest_field_device, selftest_digits};
+                      selftest_field_device, selftest_curve_device, selftest_digits};
 
 }  // namespace
 

@@ -48,6 +48,9 @@ struct CurveOps {
   // the same field ops run by a device kernel on n element pairs (device pointers)
   hipError_t (*selftest_field_device)(int which, int op, const void* d_a, const void* d_b, void* d_out, uint32_t n,
                                       hipStream_t s);
+  // the working-form group law on the device, four lanes per pair (op 0/1: quad add / double, 2/3: lane add /
+  // double, 5: [k]p by the weight kernel's double-and-add with a different k per quad)
+  hipError_t (*selftest_curve_device)(int op, const void* d_p, const void* d_q, void* d_out, uint32_t n, hipStream_t s);
   int (*selftest_digits)(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t* out, uint32_t cap);
 };
 

@@ -25,6 +25,7 @@
 //    tree (buckets cut into hundreds of pieces -- degenerate columns -- first go through a
 //    wave-per-128-pieces reduction), then the bucket weights (b+1) and a two-level tree sum.
 #pragma once
+#include "h2_curve29.hpp"
 #include "h2_curve_quad.hpp"
 #include <cstdlib>
 
@@ -36,6 +37,7 @@ constexpr uint32_t MSM_MAX_WINDOWS = 48;
 constexpr uint32_t MSM_HOT_SPAN = 256;    // keys cut into more pieces than this take the hierarchical path
 constexpr uint32_t MSM_HOT_SEG = 128;     // pieces summed by one wave of msm_hot_reduce_kernel
 constexpr uint32_t MSM_NOT_HOT = 0xFFFFFFFFu;
+constexpr uint32_t MSM_CHUNK_WAVES = 3;   // resident waves per SIMD of the accumulate kernel (159 VGPRs)
 constexpr uint32_t MSM_MAX_C = 16;        // B*4 bytes of LDS histogram must fit one CU: 2^15 * 4 = 128 KiB
 
 struct MsmGeom {
@@ -83,9 +85,7 @@ msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint3
   Xyzz<CV> cur = xyzz_from_affine(p);
   for (uint32_t w = 0; w < g.W; w++) {
     Affine<CV> a = (w == 0) ? p : xyzz_to_affine(cur);
-    U128* dst = table + 4 * ((size_t)w * n + i);
-    fe_store<B>(dst, a.x);
-    fe_store<B>(dst + 2, a.y);
+    affine29_store_table<CV>(table + 4 * ((size_t)w * n + i), a);      // working form (R' = 2^261), see h2_curve29.hpp
     if (w + 1 < g.W) {
       for (uint32_t k = 0; k < g.width[w]; k++) cur = xyzz_double(cur);
     }
@@ -256,10 +256,8 @@ msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ c
 
 // ---- accumulate: every thread adds T consecutive sorted entries ---------------------------------
 template <class CV>
-__device__ __forceinline__ Affine<CV> msm_fetch(const U128* __restrict__ table, uint32_t entry) {
-  Affine<CV> p = affine_load<CV>(table + 4 * (size_t)(entry & ~MSM_SIGN));
-  if (entry & MSM_SIGN) p.y = fe_neg(p.y);
-  return p;
+__device__ __forceinline__ Affine29<CV> msm_fetch(const U128* __restrict__ table, uint32_t entry) {
+  return affine29_load<CV>(table + 4 * (size_t)(entry & ~MSM_SIGN), (entry & MSM_SIGN) != 0);
 }
 
 // Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device.  A run (maximal stretch of one key inside the chunk) that holds the key's
@@ -268,7 +266,7 @@ template <class CV>
 __global__ void __launch_bounds__(256)
 msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ sorted_ref,
                  const uint32_t* __restrict__ chunk_first, const uint32_t* __restrict__ offsets, size_t K, uint32_t T,
-                 U128* __restrict__ bucket_sum, U128* __restrict__ head, U128* __restrict__ tail) {
+                 uint32_t* __restrict__ bucket_sum, uint32_t* __restrict__ head, uint32_t* __restrict__ tail) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t E = offsets[K];
   const uint64_t lo64 = (uint64_t)t * T;
@@ -277,7 +275,7 @@ msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ so
   uint32_t key = chunk_first[t];
   uint32_t next = offsets[key + 1];          // first entry of the following list
   bool first = true;
-  Xyzz<CV> a = Xyzz<CV>::identity();
+  Xyzz29<CV> a = Xyzz29<CV>::identity();
   U128 quad = U128{0, 0, 0, 0};
   for (uint32_t e = lo; e < hi; e++) {
     // refs are fetched as aligned 16-byte vectors whatever T is (the first one may start below lo, the last one may
@@ -287,34 +285,34 @@ msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ so
     const uint32_t ref = sel == 0 ? quad.x : sel == 1 ? quad.y : sel == 2 ? quad.z : quad.w;
     if (e >= next) {
       // the run of `key` ended inside the chunk
-      if (first && offsets[key] != lo) xyzz_store<CV>(head + 8 * (size_t)t, a);
-      else xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
+      if (first && offsets[key] != lo) xyzz29_store<CV>(head + XYZZ29_WORDS * (size_t)t, a);
+      else xyzz29_store<CV>(bucket_sum + XYZZ29_WORDS * (size_t)key, a);
       first = false;
-      a = Xyzz<CV>::identity();
+      a = Xyzz29<CV>::identity();
       do {                                  // skip empty lists
         key++;
         next = offsets[key + 1];
       } while (e >= next);
     }
-    a = xyzz_add_affine(a, msm_fetch<CV>(table, ref));
+    a = xyzz29_add_affine(a, msm_fetch<CV>(table, ref));
   }
   const bool ends_here = next == hi;
   const bool starts_here = !first || offsets[key] == lo;
-  if (starts_here && ends_here) xyzz_store<CV>(bucket_sum + 8 * (size_t)key, a);
-  else if (first) xyzz_store<CV>(head + 8 * (size_t)t, a);   // one run spanning the whole chunk, or a cut first run
-  else xyzz_store<CV>(tail + 8 * (size_t)t, a);
+  if (starts_here && ends_here) xyzz29_store<CV>(bucket_sum + XYZZ29_WORDS * (size_t)key, a);
+  else if (first) xyzz29_store<CV>(head + XYZZ29_WORDS * (size_t)t, a);   // one run spanning the whole chunk, or a cut first run
+  else xyzz29_store<CV>(tail + XYZZ29_WORDS * (size_t)t, a);
 }
 
 // shuffle an XYZZ point down by `delta` lanes
 template <class CV>
-__device__ __forceinline__ Xyzz<CV> xyzz_shfl_down(const Xyzz<CV>& p, uint32_t delta) {
-  Xyzz<CV> r;
+__device__ __forceinline__ Xyzz29<CV> xyzz_shfl_down(const Xyzz29<CV>& p, uint32_t delta) {
+  Xyzz29<CV> r;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    r.x.v[i] = (uint32_t)__shfl_down((int)p.x.v[i], delta, 64);
-    r.y.v[i] = (uint32_t)__shfl_down((int)p.y.v[i], delta, 64);
-    r.zz.v[i] = (uint32_t)__shfl_down((int)p.zz.v[i], delta, 64);
-    r.zzz.v[i] = (uint32_t)__shfl_down((int)p.zzz.v[i], delta, 64);
+  for (int i = 0; i < 9; i++) {
+    r.x.v[i] = __shfl_down(p.x.v[i], delta, 64);
+    r.y.v[i] = __shfl_down(p.y.v[i], delta, 64);
+    r.zz.v[i] = __shfl_down(p.zz.v[i], delta, 64);
+    r.zzz.v[i] = __shfl_down(p.zzz.v[i], delta, 64);
   }
   return r;
 }
@@ -322,11 +320,11 @@ __device__ __forceinline__ Xyzz<CV> xyzz_shfl_down(const Xyzz<CV>& p, uint32_t d
 // piece p of a key whose list starts at entry s and spans chunks j0..: p = 0 is chunk j0's tail (or head when the
 // list starts exactly at the chunk), p >= 1 is the head of chunk j0 + p
 template <class CV>
-__device__ __forceinline__ Xyzz<CV> msm_piece(const U128* __restrict__ head, const U128* __restrict__ tail, uint32_t s,
-                                             uint32_t j0, uint32_t T, uint32_t p) {
+__device__ __forceinline__ Xyzz29<CV> msm_piece(const uint32_t* __restrict__ head, const uint32_t* __restrict__ tail,
+                                               uint32_t s, uint32_t j0, uint32_t T, uint32_t p) {
   const uint32_t j = j0 + p;
-  const U128* src = (p == 0 && s != j0 * T) ? tail + 8 * (size_t)j : head + 8 * (size_t)j;
-  return xyzz_load<CV>(src);
+  const uint32_t* src = (p == 0 && s != j0 * T) ? tail : head;
+  return xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)j);
 }
 
 // Degenerate columns (a permutation grand product that is 1 on almost every row, an all-ones selector) put tens of
@@ -386,7 +384,7 @@ template <class CV>
 __global__ void __launch_bounds__(64)
 msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const uint32_t* __restrict__ hot_slot,
                       const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t max_tasks,
-                      const U128* __restrict__ head, const U128* __restrict__ tail, U128* __restrict__ hot_part) {
+                      const uint32_t* __restrict__ head, const uint32_t* __restrict__ tail, uint32_t* __restrict__ hot_part) {
   const uint32_t ntask = min(*task_count, max_tasks);
   const uint32_t quad = threadIdx.x >> 2;
   for (uint32_t t = blockIdx.x; t < ntask; t += gridDim.x) {
@@ -394,10 +392,10 @@ msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const ui
     const uint32_t s = offsets[key], e = offsets[key + 1];
     const uint32_t j0 = s / T, span = (e - 1) / T - j0 + 1;
     const uint32_t lo = q * MSM_HOT_SEG, hi = min(span, lo + MSM_HOT_SEG);
-    Xyzz<CV> a = Xyzz<CV>::identity();
-    for (uint32_t p = lo + quad; p < hi; p += 16) a = xyzz_add_quad(a, msm_piece<CV>(head, tail, s, j0, T, p));
-    for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_add_quad(a, xyzz_shfl_down(a, d));
-    if (threadIdx.x == 0) xyzz_store<CV>(hot_part + 8 * (size_t)(hot_slot[key] + q), a);
+    Xyzz29<CV> a = Xyzz29<CV>::identity();
+    for (uint32_t p = lo + quad; p < hi; p += 16) a = xyzz29_add_quad(a, msm_piece<CV>(head, tail, s, j0, T, p));
+    for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz29_add_quad(a, xyzz_shfl_down(a, d));
+    if (threadIdx.x == 0) xyzz29_store<CV>(hot_part + XYZZ29_WORDS * (size_t)(hot_slot[key] + q), a);
   }
 }
 
@@ -407,8 +405,9 @@ msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const ui
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g,
-                 const U128* __restrict__ bucket_sum, const U128* __restrict__ head, const U128* __restrict__ tail,
-                 const uint32_t* __restrict__ hot_slot, const U128* __restrict__ hot_part, U128* __restrict__ xsum) {
+                 const uint32_t* __restrict__ bucket_sum, const uint32_t* __restrict__ head,
+                 const uint32_t* __restrict__ tail, const uint32_t* __restrict__ hot_slot,
+                 const uint32_t* __restrict__ hot_part, uint32_t* __restrict__ xsum) {
   const uint32_t G = 1u << log_g;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> log_g;
@@ -416,46 +415,46 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
   const uint32_t quad = lane >> 2, nquad = G >> 2;
   // all lanes of a wave stay in the shuffle tree together; out-of-range keys work on identities
   const bool live = key < K;
-  Xyzz<CV> x = Xyzz<CV>::identity();
+  Xyzz29<CV> x = Xyzz29<CV>::identity();
   if (live) {
     const uint32_t s = offsets[key], e = offsets[key + 1];
     if (e > s) {
       const uint32_t j0 = s / T, j1 = (e - 1) / T;
       if (j0 == j1) {
-        if (quad == 0) x = xyzz_load<CV>(bucket_sum + 8 * key);
+        if (quad == 0) x = xyzz29_load<CV>(bucket_sum + XYZZ29_WORDS * key);
       } else if (hot_slot[key] != MSM_NOT_HOT) {
         const uint32_t nseg = (j1 - j0 + 1 + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
-        const U128* part = hot_part + 8 * (size_t)hot_slot[key];
-        for (uint32_t q = quad; q < nseg; q += nquad) x = xyzz_add_quad(x, xyzz_load<CV>(part + 8 * (size_t)q));
+        const uint32_t* part = hot_part + XYZZ29_WORDS * (size_t)hot_slot[key];
+        for (uint32_t q = quad; q < nseg; q += nquad) x = xyzz29_add_quad(x, xyzz29_load<CV>(part + XYZZ29_WORDS * (size_t)q));
       } else {
-        for (uint32_t p = quad; p <= j1 - j0; p += nquad) x = xyzz_add_quad(x, msm_piece<CV>(head, tail, s, j0, T, p));
+        for (uint32_t p = quad; p <= j1 - j0; p += nquad) x = xyzz29_add_quad(x, msm_piece<CV>(head, tail, s, j0, T, p));
       }
     }
   }
-  for (uint32_t d = G >> 1; d >= 4; d >>= 1) x = xyzz_add_quad(x, xyzz_shfl_down(x, d));
-  if (live && lane == 0) xyzz_store<CV>(xsum + 8 * key, x);
+  for (uint32_t d = G >> 1; d >= 4; d >>= 1) x = xyzz29_add_quad(x, xyzz_shfl_down(x, d));
+  if (live && lane == 0) xyzz29_store<CV>(xsum + XYZZ29_WORDS * key, x);
 }
 
 // Bucket weights: weighted[key] = (bucket + 1) * xsum[key], one QUAD per key (MSB-first double-and-add with the
 // 4-lanes-per-point arithmetic: a doubling is 3 multiplication levels deep, an addition 4).
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_weight_kernel(const U128* __restrict__ xsum, U128* __restrict__ weighted, size_t K, uint32_t bucket_mask) {
+msm_weight_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ weighted, size_t K, uint32_t bucket_mask) {
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> 2;
   if (key >= K) return;                       // whole quads leave together (K * 4 threads are launched)
-  Xyzz<CV> x = xyzz_load<CV>(xsum + 8 * key);
-  Xyzz<CV> r = Xyzz<CV>::identity();
+  Xyzz29<CV> x = xyzz29_load<CV>(xsum + XYZZ29_WORDS * key);
+  Xyzz29<CV> r = Xyzz29<CV>::identity();
   if (!x.is_identity()) {
     const uint32_t k = ((uint32_t)key & bucket_mask) + 1;
     const int top = 31 - __clz(k);
     r = x;
     for (int bit = top - 1; bit >= 0; bit--) {
-      r = xyzz_double_quad(r);
-      if ((k >> bit) & 1) r = xyzz_add_quad(r, x);
+      r = xyzz29_double_quad(r);
+      if ((k >> bit) & 1) r = xyzz29_add_quad(r, x);
     }
   }
-  if ((gt & 3) == 0) xyzz_store<CV>(weighted + 8 * key, r);
+  if ((gt & 3) == 0) xyzz29_store<CV>(weighted + XYZZ29_WORDS * key, r);
 }
 
 // ---- tree sum: out[col][blockIdx.x] = sum of the `seg` points in[col][blockIdx.x*seg ...] -------------
@@ -464,25 +463,25 @@ msm_weight_kernel(const U128* __restrict__ xsum, U128* __restrict__ weighted, si
 // level 2 sums the B/64 partials of a column in one wave.
 template <class CV>
 __global__ void __launch_bounds__(64)
-msm_tree_sum_kernel(const U128* __restrict__ in, U128* __restrict__ out, uint32_t count /* per column */,
+msm_tree_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t count /* per column */,
                     uint32_t seg, uint32_t out_per_col) {
   const uint32_t col = blockIdx.y;
   const uint32_t base = blockIdx.x * seg;
   const uint32_t end = min(base + seg, count);
-  Xyzz<CV> a = Xyzz<CV>::identity();
+  Xyzz29<CV> a = Xyzz29<CV>::identity();
   for (uint32_t idx = base + (threadIdx.x >> 2); idx < end; idx += 16)
-    a = xyzz_add_quad(a, xyzz_load<CV>(in + 8 * ((size_t)col * count + idx)));
-  for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_add_quad(a, xyzz_shfl_down(a, d));
-  if (threadIdx.x == 0) xyzz_store<CV>(out + 8 * ((size_t)col * out_per_col + blockIdx.x), a);
+    a = xyzz29_add_quad(a, xyzz29_load<CV>(in + XYZZ29_WORDS * ((size_t)col * count + idx)));
+  for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz29_add_quad(a, xyzz_shfl_down(a, d));
+  if (threadIdx.x == 0) xyzz29_store<CV>(out + XYZZ29_WORDS * ((size_t)col * out_per_col + blockIdx.x), a);
 }
 
 // ---- finish: XYZZ -> Jacobian (m points) ---------------------------------------------------------
 template <class CV>
-__global__ void msm_to_jacobian_kernel(const U128* __restrict__ in, U128* __restrict__ out_jac, uint32_t m) {
+__global__ void msm_to_jacobian_kernel(const uint32_t* __restrict__ in, U128* __restrict__ out_jac, uint32_t m) {
   const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= m) return;
   using B = typename CV::Base;
-  Xyzz<CV> p = xyzz_load<CV>(in + 8 * (size_t)col);
+  const Xyzz<CV> p = xyzz29_to_api(xyzz29_load<CV>(in + XYZZ29_WORDS * (size_t)col));
   Fe<B> x, y, z;
   xyzz_to_jacobian(p, x, y, z);
   fe_store<B>(out_jac + 6 * (size_t)col, x);
@@ -491,11 +490,11 @@ __global__ void msm_to_jacobian_kernel(const U128* __restrict__ in, U128* __rest
 }
 // XYZZ -> affine (m points), for h2_msm_batch's normalised output
 template <class CV>
-__global__ void msm_to_affine_kernel(const U128* __restrict__ in, U128* __restrict__ out_aff, uint32_t m) {
+__global__ void msm_to_affine_kernel(const uint32_t* __restrict__ in, U128* __restrict__ out_aff, uint32_t m) {
   const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= m) return;
   using B = typename CV::Base;
-  Affine<CV> a = xyzz_to_affine(xyzz_load<CV>(in + 8 * (size_t)col));
+  Affine<CV> a = xyzz_to_affine(xyzz29_to_api(xyzz29_load<CV>(in + XYZZ29_WORDS * (size_t)col)));
   fe_store<B>(out_aff + 4 * (size_t)col, a.x);
   fe_store<B>(out_aff + 4 * (size_t)col + 2, a.y);
 }
@@ -581,7 +580,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   uint64_t T = 64;
   {
     uint64_t best = ~0ull;
-    for (uint64_t w = 4; w >= 2; w--) {
+    for (uint64_t w = MSM_CHUNK_WAVES; w >= 2; w--) {
       uint64_t t = (ws.E + w * 65536 - 1) / (w * 65536);
       if (t < 8) t = 8;
       if (t > 64) continue;
@@ -618,19 +617,19 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
   ws.off_ref = o; o = h2_align256(o + ws.E * 4 + 16);             // + slack for the last 16-byte read
   ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
-  ws.off_bsum = o; o = h2_align256(o + ws.K * 128);
-  ws.off_head = o; o = h2_align256(o + ws.nchunks * 128);
-  ws.off_tail = o; o = h2_align256(o + ws.nchunks * 128);
-  ws.off_xsum = o; o = h2_align256(o + ws.K * 128);
-  ws.off_weighted = o; o = h2_align256(o + ws.K * 128);
-  ws.off_tree1 = o; o = h2_align256(o + m * ws.lvl1 * 128);
-  ws.off_tree2 = o; o = h2_align256(o + m * 128);
+  ws.off_bsum = o; o = h2_align256(o + ws.K * (XYZZ29_WORDS * 4));
+  ws.off_head = o; o = h2_align256(o + ws.nchunks * (XYZZ29_WORDS * 4));
+  ws.off_tail = o; o = h2_align256(o + ws.nchunks * (XYZZ29_WORDS * 4));
+  ws.off_xsum = o; o = h2_align256(o + ws.K * (XYZZ29_WORDS * 4));
+  ws.off_weighted = o; o = h2_align256(o + ws.K * (XYZZ29_WORDS * 4));
+  ws.off_tree1 = o; o = h2_align256(o + m * ws.lvl1 * (XYZZ29_WORDS * 4));
+  ws.off_tree2 = o; o = h2_align256(o + m * (XYZZ29_WORDS * 4));
   // hot keys: a key with span > MSM_HOT_SPAN emits ceil(span / SEG) <= span / SEG + 1 <= span / SEG + span / SPAN
   // tasks, and the spans of all keys add up to at most nchunks + K_hot <= nchunks * (1 + 1 / SPAN)
   ws.max_tasks = (uint32_t)(ws.nchunks / MSM_HOT_SEG + 2 * (ws.nchunks / MSM_HOT_SPAN) + 16);
   ws.off_hot_slot = o; o = h2_align256(o + ws.K * 4);
   ws.off_hot_tasks = o; o = h2_align256(o + (size_t)ws.max_tasks * 8);
-  ws.off_hot_part = o; o = h2_align256(o + (size_t)ws.max_tasks * 128);
+  ws.off_hot_part = o; o = h2_align256(o + (size_t)ws.max_tasks * (XYZZ29_WORDS * 4));
   ws.total = o;
   return ws;
 }
@@ -650,16 +649,16 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   uint32_t* sref = (uint32_t*)(ws_base + ws.off_ref);
   uint32_t* chunk_first = (uint32_t*)(ws_base + ws.off_key);
   uint32_t* misc = (uint32_t*)(ws_base + ws.off_misc);
-  U128* bsum = (U128*)(ws_base + ws.off_bsum);
-  U128* head = (U128*)(ws_base + ws.off_head);
-  U128* tail = (U128*)(ws_base + ws.off_tail);
-  U128* xsum = (U128*)(ws_base + ws.off_xsum);
-  U128* weighted = (U128*)(ws_base + ws.off_weighted);
-  U128* tree1 = (U128*)(ws_base + ws.off_tree1);
-  U128* tree2 = (U128*)(ws_base + ws.off_tree2);
+  uint32_t* bsum = (uint32_t*)(ws_base + ws.off_bsum);
+  uint32_t* head = (uint32_t*)(ws_base + ws.off_head);
+  uint32_t* tail = (uint32_t*)(ws_base + ws.off_tail);
+  uint32_t* xsum = (uint32_t*)(ws_base + ws.off_xsum);
+  uint32_t* weighted = (uint32_t*)(ws_base + ws.off_weighted);
+  uint32_t* tree1 = (uint32_t*)(ws_base + ws.off_tree1);
+  uint32_t* tree2 = (uint32_t*)(ws_base + ws.off_tree2);
   uint32_t* hot_slot = (uint32_t*)(ws_base + ws.off_hot_slot);
   uint32_t* hot_tasks = (uint32_t*)(ws_base + ws.off_hot_tasks);
-  U128* hot_part = (U128*)(ws_base + ws.off_hot_part);
+  uint32_t* hot_part = (uint32_t*)(ws_base + ws.off_hot_part);
   hipError_t e;
   // one memset: misc (256 B) sits directly before counts.  Nothing else needs clearing: every slot of bucket_sum /
   // head / tail that a later kernel reads has been written by the accumulate kernel (the fix-up decides from

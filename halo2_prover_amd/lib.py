@@ -64,6 +64,7 @@ SELFTEST_SYMBOLS = {
     "h2_selftest_curve_op": (_I, [_I, _I, _P, _P, _P]),
     "h2_selftest_digits": (_I, [_I, _P, _Z, _P, _U32]),
     "h2_selftest_field_op_device": (_I, [_I, _I, _P, _P, _P, _Z]),
+    "h2_selftest_curve_op_device": (_I, [_I, _I, _P, _P, _P, _Z]),
 }
 
 _lib = None

@@ -24,6 +24,11 @@ int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t 
  * pointers, one kernel launch.  op 7 = the portable CIOS product compiled for the device (cross-check),
  * op 8 = the row-ordered latency form used by the 4-lanes-per-point kernels. */
 int h2_selftest_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* the MSM's working-form group law (csrc/h2_curve29.hpp, h2_curve_quad.hpp) run by a device kernel on n pairs of
+ * affine points (host pointers, 64 bytes each, API form; out: affine), four lanes per pair.  op 0 / 1: the
+ * 4-lanes-per-point addition / doubling, 2 / 3: the one-lane forms, 4: double then add, 5: [k]p with k = the low
+ * 32 bits of q.x by the weight kernel's double-and-add (a different k per quad: divergent control flow). */
+int h2_selftest_curve_op_device(int curve, int op, const uint64_t* p, const uint64_t* q, uint64_t* out, size_t n);
 /* host run of the signed-digit window decomposition used by the MSM digits kernel.
  * scalar: Montgomery limbs; geometry chosen as for `n_for_geometry` registered bases.
  * out[0..3] = widest window c, windows W, buckets B, scalar bits; out[4 + w] = 0 or |d| | sign << 31;

@@ -266,7 +266,7 @@ def test_device_field_ops_match_oracle(h2, name):
     n = a.shape[0]
     lib = h2.load()
     out = np.zeros_like(a)
-    for op, oname in ((2, "mul"), (0, "add"), (1, "sub"), (7, "mul"), (8, "mul")):   # 7: CIOS, 8: latency (row) form
+    for op, oname in ((2, "mul"), (0, "add"), (1, "sub"), (7, "mul"), (8, "mul"), (9, "mul")):   # 7: CIOS, 8: row form, 9: 29-bit working form
         assert lib.h2_selftest_field_op_device(fid, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
         if oname == "mul":
             want = O.field_mul_many(fid, a.reshape(-1), b.reshape(-1)).reshape(n, 4)
@@ -277,3 +277,39 @@ def test_device_field_ops_match_oracle(h2, name):
     assert lib.h2_selftest_field_op_device(fid, 3, a[1:k + 1].copy().ctypes.data, b.ctypes.data, out.ctypes.data, k) == 0
     for i in range(k):
         assert O.limbs_to_int(out[i]) == f.to_mont(pow(vals[i + 1], -1, f.p))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "pallas", "vesta"])
+def test_device_group_law_on_the_working_form(h2, curve):
+    """The MSM's working representation (9 x 29-bit limbs, csrc/h2_curve29.hpp) on the device, against big integers:
+    the 4-lanes-per-point addition / doubling (ops 0, 1, 4), the one-lane forms (2, 3) and the weight kernel's
+    double-and-add with a different multiplier per quad (5) -- including P + P, P - P and identity operands."""
+    c = R.CURVES[curve]
+    cid = O.CURVE_IDS[curve]
+    L = h2.load()
+    n = 28
+    Ps = [c.mul(0x1234567 + 3 * i, c.gen) for i in range(n)]
+    Qs = [c.mul(0x7654321 + 5 * i, c.gen) for i in range(n)]
+    Qs[3] = Ps[3]                  # P + P inside an addition
+    Qs[4] = c.neg(Ps[4])           # P - P
+    Qs[5] = None                   # P + O
+    Ps[6] = None                   # O + Q
+    Ps[7] = Qs[7] = None           # O + O
+
+    def aff(pts):
+        return np.frombuffer(b"".join(c.affine_bytes(P) for P in pts), dtype=np.uint64).reshape(len(pts), 8).copy()
+
+    p, q = aff(Ps), aff(Qs)
+    out = np.zeros_like(p)
+    dbl = [c.add(a, a) for a in Ps]
+    for op, want in ((0, [c.add(a, b) for a, b in zip(Ps, Qs)]), (1, dbl), (2, [c.add(a, b) for a, b in zip(Ps, Qs)]),
+                     (3, dbl), (4, [c.add(d, b) for d, b in zip(dbl, Qs)])):
+        assert L.h2_selftest_curve_op_device(cid, op, p.ctypes.data, q.ctypes.data, out.ctypes.data, n) == 0
+        assert np.array_equal(out, aff(want)), op
+    ks = [0, 1, 2, 3, 4, 5, 6, 7, 8, 31, 32, 33, 255, 256, 257, 4095, 4096, 4097, 0xFFFF, 0x10001, 0xABCDE, 2047, 2048,
+          1023, 77, 0xFFFFFFFF, 0x80000000, 0xAAAAAAAA]
+    kq = np.zeros((n, 8), dtype=np.uint64)
+    kq[:, 0] = ks
+    kq[:, 4] = 1
+    assert L.h2_selftest_curve_op_device(cid, 5, p.ctypes.data, kq.ctypes.data, out.ctypes.data, n) == 0
+    assert np.array_equal(out, aff([c.mul(k, P) if k else None for k, P in zip(ks, Ps)]))

@@ -60,8 +60,11 @@ def test_host_field_ops_match_oracle(lib, name):
         b = vals[(7 * i + 3) % len(vals)]
         am = np.array(f.limbs(a), dtype=np.uint64)
         bm = np.array(f.limbs(b), dtype=np.uint64)
-        for op, name_ in ((0, "add"), (1, "sub"), (2, "mul")):
-            assert np.array_equal(_fop(lib, fid, op, am, bm), O.field_op(fid, name_, am, bm)), (name_, a, b)
+        for op, name_ in ((0, "add"), (1, "sub"), (2, "mul"), (9, "mul"), (10, "add"), (11, "sub")):
+            # ops 9-11: the same through the MSM's working form (9 x 29-bit limbs, R' = 2^261, h2_field29.hpp)
+            assert np.array_equal(_fop(lib, fid, op, am, bm), O.field_op(fid, name_, am, bm)), (op, name_, a, b)
+        chain = ((a - b) ** 2 - a * b - 2 * b) % f.p                     # op 12: a lazy chain, normalised once
+        assert O.limbs_to_int(_fop(lib, fid, 12, am, bm)) == f.to_mont(chain), (a, b)
         assert np.array_equal(_fop(lib, fid, 6, am), O.field_op(fid, "neg", am))
         assert np.array_equal(_fop(lib, fid, 5, am), O.field_op(fid, "from_mont", am))
         assert np.array_equal(_fop(lib, fid, 4, am), O.field_op(fid, "to_mont", am))
@@ -102,6 +105,19 @@ def test_host_curve_ops_match_bigint_reference(lib, name):
         kq = np.zeros(8, dtype=np.uint64)
         kq[0] = k
         assert np.array_equal(_cop(lib, cid, 3, _aff(c, P), kq), _aff(c, c.mul(k, P))), k
+    # ops 10-13: the same four operations on the MSM's working representation (h2_curve29.hpp)
+    assert np.array_equal(_cop(lib, cid, 10, _aff(c, P), _aff(c, Q)), _aff(c, c.add(P, Q)))
+    assert np.array_equal(_cop(lib, cid, 10, _aff(c, P), _aff(c, P)), _aff(c, c.add(P, P)))
+    assert np.array_equal(_cop(lib, cid, 10, _aff(c, P), _aff(c, c.neg(P))), ident)
+    assert np.array_equal(_cop(lib, cid, 10, ident, _aff(c, Q)), _aff(c, Q))
+    assert np.array_equal(_cop(lib, cid, 10, _aff(c, P), ident), _aff(c, P))
+    assert np.array_equal(_cop(lib, cid, 11, _aff(c, P), ident), _aff(c, c.add(P, P)))
+    assert np.array_equal(_cop(lib, cid, 12, _aff(c, P), _aff(c, Q)), _aff(c, c.add(c.add(P, Q), Q)))
+    assert np.array_equal(_cop(lib, cid, 12, _aff(c, Q), _aff(c, Q)), _aff(c, c.mul(3, Q)))
+    for k in (1, 2, 3, 0xFFFF, 0x10001, 0xFFFFFFFF, 0xAAAAAAAA, 0x80000001):
+        kq = np.zeros(8, dtype=np.uint64)
+        kq[0] = k
+        assert np.array_equal(_cop(lib, cid, 13, _aff(c, P), kq), _aff(c, c.mul(k, P))), k
     # group order: [q]G = O  (SURVEY.md section 8(a) asks for this assertion on the Pasta curves)
     assert c.mul(c.scalar.p, G) is None
 
