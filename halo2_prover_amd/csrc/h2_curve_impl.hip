@@ -153,7 +153,6 @@ __global__ void selftest_field_kernel(int op, const U128* a_, const U128* b_, U1
     case 4: r = fe_to_mont(a); break;
     case 5: r = fe_from_mont(a); break;
     case 7: r = fe_mul_cios(a, b); break;
-    case 8: r = fe_mul_lat(a, b); break;
     case 9: r = fe29_to_api(fe29_mul(fe29_from_api(a), fe29_from_api(b))); break;
     default: r = fe_neg(a); break;
   }

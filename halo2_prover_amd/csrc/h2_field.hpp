@@ -254,167 +254,12 @@ __device__ __forceinline__ Fe<FP> fe_mul_comba(const Fe<FP>& a, const Fe<FP>& b)
   return r;
 }
 
-// Latency form of the same product, for kernels that run ONE wave per SIMD (the MSM tails on quads,
-// h2_curve_quad.hpp).  fe_mul_comba threads all ~90 multiply-adds through one accumulator, so a lone wave waits
-// out the full latency of every v_mad_u64_u32 (measured 1600-2350 cycles per product against 1116 when four waves
-// share the SIMD).  Here every column K of a*b + m*p has its OWN accumulator: the 64 limb products are issued row
-// by row, so consecutive multiply-adds hit different columns and are independent; only the reduction walks the
-// columns in order (carry in, m[K], carry out), scattering m[K] * p[J] into the columns above it as soon as m[K]
-// exists.  ~6 % more VALU instructions but a fifth of the s_nops, ~45 more live registers -- which a lone wave has to
-// spare.  Measured in the throughput-bound kernels instead of fe_mul_comba it is SLOWER (accumulate kernel 0.437 ->
-// 0.460 ms, NTT passes 0.63 -> 0.70 ms per step): there other waves fill the s_nop slots and only the VALU count matters.
-namespace detail {
-// Blocks of independent multiply-adds: the carry of each v_mad_u64_u32 goes to its OWN scalar register pair and is
-// folded into the column's carry count only after the whole block has been issued, so the in-order pipeline never
-// waits on the instruction just before (one mad + its addc back to back would).
-__device__ __forceinline__ void mul4_first(uint64_t* acc, uint32_t a, const uint32_t* b) {
-  asm("v_mad_u64_u32 %0, vcc, %4, %5, 0\n\t"
-      "v_mad_u64_u32 %1, vcc, %4, %6, 0\n\t"
-      "v_mad_u64_u32 %2, vcc, %4, %7, 0\n\t"
-      "v_mad_u64_u32 %3, vcc, %4, %8, 0"
-      : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
-      : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "vcc");
-}
-__device__ __forceinline__ void mac4_vv(uint64_t* acc, uint32_t* cnt, uint32_t a, const uint32_t* b) {
-  uint64_t c0, c1, c2, c3;
-  asm("v_mad_u64_u32 %0, %8, %12, %13, %0\n\t"
-      "v_mad_u64_u32 %1, %9, %12, %14, %1\n\t"
-      "v_mad_u64_u32 %2, %10, %12, %15, %2\n\t"
-      "v_mad_u64_u32 %3, %11, %12, %16, %3\n\t"
-      "v_addc_co_u32_e64 %4, %8, 0, %4, %8\n\t"
-      "v_addc_co_u32_e64 %5, %9, 0, %5, %9\n\t"
-      "v_addc_co_u32_e64 %6, %10, 0, %6, %10\n\t"
-      "v_addc_co_u32_e64 %7, %11, 0, %7, %11"
-      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]), "+v"(cnt[3]),
-        "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
-      : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
-}
-// three accumulating columns and a fresh fourth (the last product of rows 1..7 opens column I + 7)
-__device__ __forceinline__ void mac3_vv_first(uint64_t* acc, uint32_t* cnt, uint32_t a, const uint32_t* b) {
-  uint64_t c0, c1, c2;
-  asm("v_mad_u64_u32 %0, %7, %10, %11, %0\n\t"
-      "v_mad_u64_u32 %1, %8, %10, %12, %1\n\t"
-      "v_mad_u64_u32 %2, %9, %10, %13, %2\n\t"
-      "v_mad_u64_u32 %3, vcc, %10, %14, 0\n\t"
-      "v_addc_co_u32_e64 %4, %7, 0, %4, %7\n\t"
-      "v_addc_co_u32_e64 %5, %8, 0, %5, %8\n\t"
-      "v_addc_co_u32_e64 %6, %9, 0, %6, %9"
-      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "=&v"(acc[3]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]),
-        "=&s"(c0), "=&s"(c1), "=&s"(c2)
-      : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "vcc");
-}
-// m * (four / three consecutive modulus limbs), limbs as scalar constants
-__device__ __forceinline__ void mac4_vs(uint64_t* acc, uint32_t* cnt, uint32_t m, uint32_t p0, uint32_t p1, uint32_t p2,
-                                        uint32_t p3) {
-  uint64_t c0, c1, c2, c3;
-  asm("v_mad_u64_u32 %0, %8, %12, %13, %0\n\t"
-      "v_mad_u64_u32 %1, %9, %12, %14, %1\n\t"
-      "v_mad_u64_u32 %2, %10, %12, %15, %2\n\t"
-      "v_mad_u64_u32 %3, %11, %12, %16, %3\n\t"
-      "v_addc_co_u32_e64 %4, %8, 0, %4, %8\n\t"
-      "v_addc_co_u32_e64 %5, %9, 0, %5, %9\n\t"
-      "v_addc_co_u32_e64 %6, %10, 0, %6, %10\n\t"
-      "v_addc_co_u32_e64 %7, %11, 0, %7, %11"
-      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]), "+v"(cnt[3]),
-        "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
-      : "v"(m), "s"(p0), "s"(p1), "s"(p2), "s"(p3));
-}
-__device__ __forceinline__ void mac3_vs(uint64_t* acc, uint32_t* cnt, uint32_t m, uint32_t p0, uint32_t p1, uint32_t p2) {
-  uint64_t c0, c1, c2;
-  asm("v_mad_u64_u32 %0, %6, %9, %10, %0\n\t"
-      "v_mad_u64_u32 %1, %7, %9, %11, %1\n\t"
-      "v_mad_u64_u32 %2, %8, %9, %12, %2\n\t"
-      "v_addc_co_u32_e64 %3, %6, 0, %3, %6\n\t"
-      "v_addc_co_u32_e64 %4, %7, 0, %4, %7\n\t"
-      "v_addc_co_u32_e64 %5, %8, 0, %5, %8"
-      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]),
-        "=&s"(c0), "=&s"(c1), "=&s"(c2)
-      : "v"(m), "s"(p0), "s"(p1), "s"(p2));
-}
-template <class FP, int I>
-__device__ __forceinline__ void rows_ab(uint64_t* acc, uint32_t* cnt, const uint32_t* a, const uint32_t* b) {
-  if constexpr (I == 0) {
-    mul4_first(acc, a[0], b);
-    mul4_first(acc + 4, a[0], b + 4);
-    rows_ab<FP, 1>(acc, cnt, a, b);
-  } else if constexpr (I < 8) {
-    mac4_vv(acc + I, cnt + I, a[I], b);
-    mac3_vv_first(acc + I + 4, cnt + I + 4, a[I], b + 4);
-    rows_ab<FP, I + 1>(acc, cnt, a, b);
-  }
-}
-// a limb that needs a real multiply (0, 1 and powers of two are folded by mac_modulus)
-template <class FP, int J>
-constexpr bool limb_is_mul() {
-  if constexpr (J > 7) {
-    return false;
-  } else {
-    constexpr uint32_t pj = FP::P(J);
-    return pj != 0 && (pj & (pj - 1)) != 0;
-  }
-}
-// columns K + J0 .. K + J0 + N - 1 += m * p[J0 ..]
-template <class FP, int K, int J0, int N>
-__device__ __forceinline__ void scatter_mp(uint64_t* acc, uint32_t* cnt, uint32_t m) {
-  if constexpr (N == 4 && limb_is_mul<FP, J0>() && limb_is_mul<FP, J0 + 1>() && limb_is_mul<FP, J0 + 2>() &&
-                limb_is_mul<FP, J0 + 3>()) {
-    mac4_vs(acc + K + J0, cnt + K + J0, m, FP::P(J0), FP::P(J0 + 1), FP::P(J0 + 2), FP::P(J0 + 3));
-  } else if constexpr (N == 4 && !limb_is_mul<FP, J0>() && limb_is_mul<FP, J0 + 1>() && limb_is_mul<FP, J0 + 2>() &&
-                       limb_is_mul<FP, J0 + 3>()) {
-    mac_modulus<FP, J0>(acc[K + J0], cnt[K + J0], m);      // the Pasta shape: p[0] = 1, p[1..3] full limbs
-    mac3_vs(acc + K + J0 + 1, cnt + K + J0 + 1, m, FP::P(J0 + 1), FP::P(J0 + 2), FP::P(J0 + 3));
-  } else {
-    mac_modulus<FP, J0>(acc[K + J0], cnt[K + J0], m);
-    if constexpr (N > 1) scatter_mp<FP, K, J0 + 1, N - 1>(acc, cnt, m);
-  }
-}
-template <class FP, int K>
-__device__ __forceinline__ void reduce_cols(uint64_t* acc, uint32_t* cnt, uint64_t& carry, uint32_t* t) {
-  if constexpr (K < 16) {
-    add64(acc[K], cnt[K], carry);
-    if constexpr (K < 8) {
-      const uint32_t m = (uint32_t)acc[K] * FP::INV;
-      scatter_mp<FP, K, 0, 4>(acc, cnt, m);       // limb 0 clears the low word of column K
-      scatter_mp<FP, K, 4, 4>(acc, cnt, m);
-    } else {
-      t[K - 8] = (uint32_t)acc[K];
-    }
-    carry = (acc[K] >> 32) | ((uint64_t)cnt[K] << 32);
-    reduce_cols<FP, K + 1>(acc, cnt, carry, t);
-  }
-}
-}  // namespace detail
-
-template <class FP>
-__device__ __forceinline__ Fe<FP> fe_mul_rows(const Fe<FP>& a, const Fe<FP>& b) {
-  uint64_t acc[16];
-  uint32_t cnt[16], t[9];
-#pragma unroll
-  for (int k = 0; k < 16; k++) cnt[k] = 0;
-  acc[15] = 0;                                     // column 15 only receives carries
-  detail::rows_ab<FP, 0>(acc, cnt, a.v, b.v);
-  uint64_t carry = 0;
-  detail::reduce_cols<FP, 0>(acc, cnt, carry, t);
-  t[8] = (uint32_t)carry;
-  Fe<FP> r;
-  fe_reduce_once<FP>(r.v, t, t[8]);
-  return r;
-}
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <class FP>
 H2_HD Fe<FP> fe_mul(const Fe<FP>& a, const Fe<FP>& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return fe_mul_comba(a, b);
-#else
-  return fe_mul_cios(a, b);
-#endif
-}
-// the product for lone-wave (latency-bound) kernels
-template <class FP>
-H2_HD Fe<FP> fe_mul_lat(const Fe<FP>& a, const Fe<FP>& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return fe_mul_rows(a, b);
 #else
   return fe_mul_cios(a, b);
 #endif

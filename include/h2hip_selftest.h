@@ -22,7 +22,7 @@ int h2_selftest_field_op(int field, int op, const uint64_t a[4], const uint64_t 
 int h2_selftest_curve_op(int curve, int op, const uint64_t p[8], const uint64_t q[8], uint64_t out[8]);
 /* The same field ops through the DEVICE instantiation (gfx950 Comba multiplier): n element pairs, host
  * pointers, one kernel launch.  op 7 = the portable CIOS product compiled for the device (cross-check),
- * op 8 = the row-ordered latency form used by the 4-lanes-per-point kernels. */
+ * op 9 = the product through the MSM's 29-bit working form. */
 int h2_selftest_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* the MSM's working-form group law (csrc/h2_curve29.hpp, h2_curve_quad.hpp) run by a device kernel on n pairs of
  * affine points (host pointers, 64 bytes each, API form; out: affine), four lanes per pair.  op 0 / 1: the
