@@ -437,6 +437,9 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
 
 // Bucket weights: weighted[key] = (bucket + 1) * xsum[key], one QUAD per key (MSB-first double-and-add with the
 // 4-lanes-per-point arithmetic: a doubling is 3 multiplication levels deep, an addition 4).
+// (A signed non-adjacent form of the multiplier was measured: slower.  A wave holds 16 quads with 16 different
+// multipliers, so some quad adds at nearly every bit whatever the recoding, and the +x / -x cases then run one after
+// the other.)
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_weight_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ weighted, size_t K, uint32_t bucket_mask) {
