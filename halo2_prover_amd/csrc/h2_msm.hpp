@@ -37,6 +37,7 @@ constexpr uint32_t MSM_MAX_WINDOWS = 48;
 constexpr uint32_t MSM_HOT_SPAN = 256;    // keys cut into more pieces than this take the hierarchical path
 constexpr uint32_t MSM_HOT_SEG = 128;     // pieces summed by one wave of msm_hot_reduce_kernel
 constexpr uint32_t MSM_NOT_HOT = 0xFFFFFFFFu;
+constexpr uint32_t MSM_SORT_THREADS = 1024;   // block size of the digits / scatter kernels
 constexpr uint32_t MSM_CHUNK_WAVES = 3;   // resident waves per SIMD of the accumulate kernel (159 VGPRs)
 constexpr uint32_t MSM_MAX_C = 16;        // B*4 bytes of LDS histogram must fit one CU: 2^15 * 4 = 128 KiB
 
@@ -115,7 +116,7 @@ H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w,
 // digits[(col*W + w)*n + i] = 0 | (|d| | sign<<31);  counts[col*B + |d|-1] += 1 through an LDS
 // histogram (one global atomic per block and non-empty bucket).  grid = (tiles, m), dynamic LDS B*4.
 template <class CV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
                   uint32_t n, size_t col_stride /* elements */, uint32_t tile, MsmGeom g) {
   using S = typename CV::Scalar;
@@ -220,7 +221,7 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
 // sorted_ref[pos] = (w * n_bases + i) | sign.  Only ONE word per entry is written: every scattered 4-byte store
 // costs a 64-byte sector at the memory side (measured: 8x write amplification), so the entry's key is not stored --
 // the accumulate kernel recovers it from `offsets`.
-static __global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(1024)
 msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
                    uint32_t* __restrict__ sorted_ref, uint32_t n, uint32_t n_bases, uint32_t tile, MsmGeom g) {
   extern __shared__ uint32_t hist[];
@@ -608,6 +609,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   const size_t dense = (size_t)2 * g.B / g.W;
   if (tile < dense) tile = dense;
   if (tile < 256) tile = 256;
+  tile *= 2;   // measured with 1024-thread blocks (MSM_SORT_THREADS): longer runs per (tile, bucket), fewer sector writes
   if (tile > n) tile = n;
   ws.tile = (uint32_t)tile;
   ws.lvl1 = (g.B + MSM_TREE_SEG - 1) / MSM_TREE_SEG;
@@ -675,14 +677,14 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
                                  (int)lds)) != hipSuccess) return e;
   }
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
-  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(256), lds, stream, d_scalars, digits,
+  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, digits,
                      counts, (uint32_t)n, n, ws.tile, g);
   // (a single-block scan for small K was measured: 21 us against 14 us for these three launches)
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      cursor, ws.K);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(256), lds, stream, digits, cursor, sref,
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, digits, cursor, sref,
                      (uint32_t)n, n_bases, ws.tile, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
