@@ -118,7 +118,8 @@ H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w,
 template <class CV>
 __global__ void __launch_bounds__(1024)
 msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
-                  uint32_t n, size_t col_stride /* elements */, uint32_t tile, MsmGeom g) {
+                  uint32_t* __restrict__ tile_base, uint32_t n, size_t col_stride /* elements */, uint32_t tile,
+                  MsmGeom g) {
   using S = typename CV::Scalar;
   extern __shared__ uint32_t hist[];
   const uint32_t col = blockIdx.y;
@@ -135,9 +136,11 @@ msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ digit
     }
   }
   __syncthreads();
+  // the value the atomic returns is where this tile's entries start inside the bucket's list: kept for the scatter
+  uint32_t* tb = tile_base + ((size_t)col * gridDim.x + blockIdx.x) * g.B;
   for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) {
     const uint32_t h = hist[b];
-    if (h) atomicAdd(&counts[(size_t)col * g.B + b], h);
+    tb[b] = h ? atomicAdd(&counts[(size_t)col * g.B + b], h) : 0u;
   }
 }
 
@@ -185,9 +188,9 @@ scan_blocksums_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out) {
   }
   if (threadIdx.x == 0) *total_out = carry;
 }
-// offsets[i] = exclusive prefix (offsets[K] = total); cursor[i] = same (scatter cursors)
+// offsets[i] = exclusive prefix (offsets[K] = total)
 static __global__ void __launch_bounds__(256)
-scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor, size_t K) {
+scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offsets, size_t K) {
   __shared__ uint32_t sh[256];
   const size_t base = (size_t)blockIdx.x * SCAN_BLOCK;
   uint32_t v[4], s = 0;
@@ -209,7 +212,6 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
     const size_t idx = base + threadIdx.x * 4 + k;
     if (idx < K) {
       offsets[idx] = run;
-      cursor[idx] = run;
     }
     run += v[k];
     if (idx + 1 == K) offsets[K] = run;
@@ -217,31 +219,21 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
 }
 
 // ---- scatter: same tiling as the digits kernel.  LDS histogram of the tile, one global atomic per
-// non-empty bucket reserves the tile's range in the bucket's list, then LDS cursors place the entries.
+// (the tile's range in every bucket's list was reserved by the digits kernel), then LDS cursors place the entries.
 // sorted_ref[pos] = (w * n_bases + i) | sign.  Only ONE word per entry is written: every scattered 4-byte store
 // costs a 64-byte sector at the memory side (measured: 8x write amplification), so the entry's key is not stored --
 // the accumulate kernel recovers it from `offsets`.
 static __global__ void __launch_bounds__(1024)
-msm_scatter_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
-                   uint32_t* __restrict__ sorted_ref, uint32_t n, uint32_t n_bases, uint32_t tile, MsmGeom g) {
+msm_scatter_kernel(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ offsets,
+                   const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ sorted_ref, uint32_t n,
+                   uint32_t n_bases, uint32_t tile, MsmGeom g) {
   extern __shared__ uint32_t hist[];
   const uint32_t col = blockIdx.y;
-  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = 0;
+  // LDS cursors: list start + this tile's base inside the list (handed out by the digits kernel's atomics)
+  const uint32_t* tb = tile_base + ((size_t)col * gridDim.x + blockIdx.x) * g.B;
+  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = offsets[(size_t)col * g.B + b] + tb[b];
   __syncthreads();
   const uint32_t lo = blockIdx.x * tile, hi = min(lo + tile, n);
-  for (uint32_t w = 0; w < g.W; w++) {
-    const uint32_t* d = digits + ((size_t)col * g.W + w) * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      const uint32_t enc = d[i];
-      if (enc) atomicAdd(&hist[(enc & ~MSM_SIGN) - 1], 1u);
-    }
-  }
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) {
-    const uint32_t h = hist[b];
-    if (h) hist[b] = atomicAdd(&cursor[(size_t)col * g.B + b], h);  // now: next free position of this tile
-  }
-  __syncthreads();
   for (uint32_t w = 0; w < g.W; w++) {
     const uint32_t* d = digits + ((size_t)col * g.W + w) * n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -567,7 +559,7 @@ struct MsmWorkspace {
   uint32_t log_g;       // lanes per key in the fix-up kernel = 2^log_g
   uint32_t tile;        // scalars per block in the digits / scatter kernels
   uint32_t lvl1;        // partials per column after the first tree level
-  size_t off_digits, off_counts, off_offsets, off_cursor, off_blocksums, off_ref, off_key, off_misc, off_bsum,
+  size_t off_digits, off_counts, off_offsets, off_tile_base, off_blocksums, off_ref, off_key, off_misc, off_bsum,
       off_head, off_tail, off_xsum, off_weighted, off_tree1, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
   uint32_t max_tasks;
 };
@@ -618,7 +610,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_misc = o; o += 256;                                      // misc[0] = hot task counter; zeroed with counts
   ws.off_counts = o; o = h2_align256(o + ws.K * 4);
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
-  ws.off_cursor = o; o = h2_align256(o + ws.K * 4);
+  ws.off_tile_base = o; o = h2_align256(o + ((n + ws.tile - 1) / ws.tile) * ws.K * 4);   // tiles x (m * B) words
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
   ws.off_ref = o; o = h2_align256(o + ws.E * 4 + 16);             // + slack for the last 16-byte read
   ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
@@ -649,7 +641,7 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   uint32_t* digits = (uint32_t*)(ws_base + ws.off_digits);
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
-  uint32_t* cursor = (uint32_t*)(ws_base + ws.off_cursor);
+  uint32_t* tile_base = (uint32_t*)(ws_base + ws.off_tile_base);
   uint32_t* blocksums = (uint32_t*)(ws_base + ws.off_blocksums);
   uint32_t* sref = (uint32_t*)(ws_base + ws.off_ref);
   uint32_t* chunk_first = (uint32_t*)(ws_base + ws.off_key);
@@ -678,13 +670,13 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   }
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
   hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, digits,
-                     counts, (uint32_t)n, n, ws.tile, g);
+                     counts, tile_base, (uint32_t)n, n, ws.tile, g);
   // (a single-block scan for small K was measured: 21 us against 14 us for these three launches)
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
-                     cursor, ws.K);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, digits, cursor, sref,
+                     ws.K);
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, digits, offsets, tile_base, sref,
                      (uint32_t)n, n_bases, ws.tile, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
