@@ -113,13 +113,13 @@ H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w,
   return raw;
 }
 
-// digits[(col*W + w)*n + i] = 0 | (|d| | sign<<31);  counts[col*B + |d|-1] += 1 through an LDS
-// histogram (one global atomic per block and non-empty bucket).  grid = (tiles, m), dynamic LDS B*4.
+// Count pass: every scalar's signed digits (0 or |d| | sign<<31) go into an LDS histogram of the tile;
+// counts[col*B + |d|-1] += the tile's count with one RETURNING global atomic per non-empty bucket, whose result --
+// where this tile's entries start inside the bucket's list -- is kept in tile_base.  grid = (tiles, m), LDS B*4.
 template <class CV>
 __global__ void __launch_bounds__(1024)
-msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ digits, uint32_t* __restrict__ counts,
-                  uint32_t* __restrict__ tile_base, uint32_t n, size_t col_stride /* elements */, uint32_t tile,
-                  MsmGeom g) {
+msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base,
+                  uint32_t n, size_t col_stride /* elements */, uint32_t tile, MsmGeom g) {
   using S = typename CV::Scalar;
   extern __shared__ uint32_t hist[];
   const uint32_t col = blockIdx.y;
@@ -132,7 +132,6 @@ msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ digit
     for (uint32_t w = 0; w < g.W; w++) {
       const uint32_t enc = msm_digit_step(s.v, g, w, carry);
       if (enc) atomicAdd(&hist[(enc & ~MSM_SIGN) - 1], 1u);
-      digits[((size_t)col * g.W + w) * n + i] = enc;
     }
   }
   __syncthreads();
@@ -218,15 +217,17 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
   }
 }
 
-// ---- scatter: same tiling as the digits kernel.  LDS histogram of the tile, one global atomic per
-// (the tile's range in every bucket's list was reserved by the digits kernel), then LDS cursors place the entries.
+// ---- scatter: same tiling as the digits kernel, which already reserved the tile's range in every bucket's list:
+// LDS cursors = list start + tile base, then one LDS atomic and one store per entry.
 // sorted_ref[pos] = (w * n_bases + i) | sign.  Only ONE word per entry is written: every scattered 4-byte store
 // costs a 64-byte sector at the memory side (measured: 8x write amplification), so the entry's key is not stored --
 // the accumulate kernel recovers it from `offsets`.
-static __global__ void __launch_bounds__(1024)
-msm_scatter_kernel(const uint32_t* __restrict__ digits, const uint32_t* __restrict__ offsets,
+template <class CV>
+__global__ void __launch_bounds__(1024)
+msm_scatter_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict__ offsets,
                    const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ sorted_ref, uint32_t n,
-                   uint32_t n_bases, uint32_t tile, MsmGeom g) {
+                   size_t col_stride /* elements */, uint32_t n_bases, uint32_t tile, MsmGeom g) {
+  using S = typename CV::Scalar;
   extern __shared__ uint32_t hist[];
   const uint32_t col = blockIdx.y;
   // LDS cursors: list start + this tile's base inside the list (handed out by the digits kernel's atomics)
@@ -234,13 +235,14 @@ msm_scatter_kernel(const uint32_t* __restrict__ digits, const uint32_t* __restri
   for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = offsets[(size_t)col * g.B + b] + tb[b];
   __syncthreads();
   const uint32_t lo = blockIdx.x * tile, hi = min(lo + tile, n);
-  for (uint32_t w = 0; w < g.W; w++) {
-    const uint32_t* d = digits + ((size_t)col * g.W + w) * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      const uint32_t enc = d[i];
+  // the digits are recomputed rather than stored by the first kernel: 32 bytes of scalar instead of 4 W bytes of digits
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < g.W; w++) {
+      const uint32_t enc = msm_digit_step(s.v, g, w, carry);
       if (enc) {
-        const uint32_t b = (enc & ~MSM_SIGN) - 1;
-        const uint32_t pos = atomicAdd(&hist[b], 1u);
+        const uint32_t pos = atomicAdd(&hist[(enc & ~MSM_SIGN) - 1], 1u);
         sorted_ref[pos] = (w * n_bases + i) | (enc & MSM_SIGN);
       }
     }
@@ -559,7 +561,7 @@ struct MsmWorkspace {
   uint32_t log_g;       // lanes per key in the fix-up kernel = 2^log_g
   uint32_t tile;        // scalars per block in the digits / scatter kernels
   uint32_t lvl1;        // partials per column after the first tree level
-  size_t off_digits, off_counts, off_offsets, off_tile_base, off_blocksums, off_ref, off_key, off_misc, off_bsum,
+  size_t off_counts, off_offsets, off_tile_base, off_blocksums, off_ref, off_key, off_misc, off_bsum,
       off_head, off_tail, off_xsum, off_weighted, off_tree1, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
   uint32_t max_tasks;
 };
@@ -606,7 +608,6 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.tile = (uint32_t)tile;
   ws.lvl1 = (g.B + MSM_TREE_SEG - 1) / MSM_TREE_SEG;
   size_t o = 0;
-  ws.off_digits = o; o = h2_align256(o + ws.E * 4);
   ws.off_misc = o; o += 256;                                      // misc[0] = hot task counter; zeroed with counts
   ws.off_counts = o; o = h2_align256(o + ws.K * 4);
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
@@ -638,7 +639,6 @@ template <class CV>
 inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_scalars, size_t n, size_t m,
                              const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-  uint32_t* digits = (uint32_t*)(ws_base + ws.off_digits);
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
   uint32_t* tile_base = (uint32_t*)(ws_base + ws.off_tile_base);
@@ -665,19 +665,19 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   if (lds > 48 * 1024) {
     if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds)) != hipSuccess) return e;
   }
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
-  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, digits,
-                     counts, tile_base, (uint32_t)n, n, ws.tile, g);
+  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, counts,
+                     tile_base, (uint32_t)n, n, ws.tile, g);
   // (a single-block scan for small K was measured: 21 us against 14 us for these three launches)
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      ws.K);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, digits, offsets, tile_base, sref,
-                     (uint32_t)n, n_bases, ws.tile, g);
+  hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
+                     tile_base, sref, (uint32_t)n, n, n_bases, ws.tile, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
   if (ev_start) (void)hipEventRecord(ev_start, stream);
