@@ -187,6 +187,41 @@ scan_blocksums_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out) {
   }
   if (threadIdx.x == 0) *total_out = carry;
 }
+// The same scan in ONE block for K <= SCAN_LDS_MAX (every proof-sized batch): the counts are staged in LDS with
+// coalesced loads, thread t scans `per` consecutive LDS words, the 1024 partial sums are scanned with shuffles, and
+// the offsets leave coalesced.  (A first single-block version that read global memory with per-thread strides took
+// 21 us against 14 us for the three launches below.)
+constexpr uint32_t SCAN_LDS_MAX = 32 * 1024;
+static __global__ void __launch_bounds__(1024)
+scan_lds_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ offsets, uint32_t K, uint32_t per) {
+  extern __shared__ uint32_t buf[];            // K words (+1 spare per 32 to spread banks is not needed: per is odd)
+  __shared__ uint32_t wave_sum[16];
+  for (uint32_t i = threadIdx.x; i < K; i += 1024) buf[i] = in[i];
+  __syncthreads();
+  const uint32_t lo = threadIdx.x * per, hi = min(K, lo + per);
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += buf[i];
+  // inclusive scan of s over the block: within the wave by shuffles, across the 16 waves through LDS
+  uint32_t incl = s;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; w++) base += wave_sum[w];
+  uint32_t run = base + incl - s;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t v = buf[i];
+    buf[i] = run;
+    run += v;
+  }
+  if (threadIdx.x == 1023) offsets[K] = run;   // the last thread's running total is the grand total
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < K; i += 1024) offsets[i] = buf[i];
+}
 // offsets[i] = exclusive prefix (offsets[K] = total)
 static __global__ void __launch_bounds__(256)
 scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offsets, size_t K) {
@@ -671,11 +706,18 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
   hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, counts,
                      tile_base, (uint32_t)n, n, ws.tile, g);
-  // (a single-block scan for small K was measured: 21 us against 14 us for these three launches)
+  if (ws.K <= SCAN_LDS_MAX) {
+    uint32_t per = (uint32_t)((ws.K + 1023) / 1024);
+    per |= 1u;                                 // odd stride: the per-thread LDS walks do not collide on banks
+    if ((e = hipFuncSetAttribute((const void*)scan_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(SCAN_LDS_MAX * 4))) != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_lds_kernel, dim3(1), dim3(1024), ws.K * 4, stream, counts, offsets, (uint32_t)ws.K, per);
+  } else {
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      ws.K);
+  }
   hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
                      tile_base, sref, (uint32_t)n, n, n_bases, ws.tile, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
