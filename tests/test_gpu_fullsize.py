@@ -8,6 +8,7 @@ golden params fixtures through ParamsKZG.
   MSM(a, [s^i]G) = (sum_i a_i s^i) G with the scalar from the oracle's eval_polynomial.
 * column groups: a batch whose sort would not fit 32-bit entry indices is run in groups of columns
   (H2_MSM_MAX_ENTRIES forces that path at a small size) and must equal the ungrouped result.
+* config 5's per-GPU shape itself: 8 columns of 2^24 through the column groups, and NTT 2^24 x 2 columns.
 * NTT n = 2^22 (three passes) and the 64-column batch shape of config 5 at reduced n: iNTT(NTT(a)) = n a,
   linearity, and A[0] = sum(a).
 """
@@ -219,3 +220,63 @@ def test_ntt_2_22_and_batch_properties(h2):
         if log_n == 16:
             want = O.best_fft(fid, a[5], w, log_n, threads=8).reshape(n, 4)
             assert np.array_equal(fwd[5], want)
+
+
+def test_config5_per_gpu_shape_2_24(h2):
+    """BASELINE.json config 5, one GPU's share: 8 columns of 2^24 rows.  The MSM batch exceeds 2^31 sort entries and
+    runs in column groups (known answer: every column is the same dense column, so all eight commitments equal
+    (sum_i a_i s^i) G); the NTT of 2 columns of 2^24 (three passes) is checked through A[0] = sum(a) on a sparse
+    column, linearity against a second column, and the round trip."""
+    import torch
+    curve = "pallas"
+    cid = O.CURVE_IDS[curve]
+    fid = O.CURVE_SCALAR_FIELD[cid]
+    fs = R.CURVES[curve].scalar
+    n, m = 1 << 24, 8
+    s = 0x1F83D9ABFB41BD6B5BE0CD19137E2179A54FF53A5F1D36F1510E527FADE682D1 % fs.p
+    g = srs(h2, curve, s, n)
+    gen = g[0].cpu().numpy().view(np.uint64)
+    bases = h2.Bases.from_device(curve, g.data_ptr(), n)
+    try:
+        assert m * bases.plan()["windows"] * n >= 1 << 31          # really more than one launch can sort
+        dense = O.synth_scalars(fid, 0x48324D5300000501, n).reshape(n, 4)
+        d1 = torch.from_numpy(dense.view(np.int64)).cuda()
+        cols = d1.unsqueeze(0).expand(m, n, 4).contiguous()
+        out = torch.zeros((m, 12), dtype=torch.int64, device="cuda")
+        bases.msm_device(cols.data_ptr(), n, m, out.data_ptr())
+        torch.cuda.synchronize()
+        del cols
+        res = out.cpu().numpy().view(np.uint64)
+        want = O.to_affine(cid, O.scalar_mul(cid, O.eval_polynomial(fid, dense, L(fs, s)), gen))
+        for j in range(m):
+            assert np.array_equal(O.to_affine(cid, res[j]), want), j
+    finally:
+        bases.release()
+    del g
+    torch.cuda.empty_cache()
+    # NTT 2^24 x 2 columns: column 0 sparse (64 + 6 non-zero rows), column 1 dense
+    log_n = 24
+    a = np.zeros((2, n, 4), dtype=np.uint64)
+    a[0, :64] = dense[:64]
+    a[0, n - 6:] = dense[n - 6:]
+    a[1] = dense
+    w, winv = L(fs, fs.omega(log_n)), L(fs, pow(fs.omega(log_n), -1, fs.p))
+    d = torch.from_numpy(a.view(np.int64)).cuda()
+    h2.ntt_device(d.data_ptr(), 2, w, log_n, curve)
+    torch.cuda.synchronize()
+    rows = np.array([0, 1, 12345, n // 2, n - 1])
+    fwd = d[:, torch.from_numpy(rows).cuda()].cpu().numpy().view(np.uint64).reshape(2, len(rows), 4)
+    nz = [i for i in list(range(64)) + list(range(n - 6, n))]
+    vals = [fs.from_mont(O.limbs_to_int(dense[i])) for i in nz]
+    wv = fs.omega(log_n)
+    for r, k in enumerate(rows):                                   # A[k] = sum_j a[j] w^(jk), 70 terms
+        want = sum(v * pow(wv, (j * int(k)) % n, fs.p) for v, j in zip(vals, nz)) % fs.p
+        assert fs.from_mont(O.limbs_to_int(fwd[0][r])) == want, k
+    h2.ntt_device(d.data_ptr(), 2, winv, log_n, curve)
+    torch.cuda.synchronize()
+    sample = np.random.RandomState(2).randint(0, n, size=64)
+    back = d[:, torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint64).reshape(2, 64, 4)
+    n_m = L(fs, n)
+    for col in (0, 1):
+        want = O.field_mul_many(fid, a[col][sample].reshape(-1), np.tile(n_m, 64)).reshape(64, 4)
+        assert np.array_equal(back[col], want)
