@@ -75,7 +75,11 @@ class EvaluationDomain:
         return _limbs(v % self.p * self.R % self.p)
 
     def _stream(self):
+        """the caller's current stream as a raw handle (the library orders its launches on it)"""
         import torch
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # ~0.3 us against ~9 us for the object
+        if raw is not None:
+            return ctypes.c_void_p(raw(torch.cuda.current_device()))
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     @staticmethod

@@ -53,6 +53,23 @@ def _limbs_of(vals):
     return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
 
 
+class _Col(list):
+    """A length-n host column of canonical integers, zero except where it was written; it remembers those rows, so
+    that uploading it does not have to scan 2^k entries (witness columns use a few dozen rows of 65 536)."""
+    __slots__ = ("touched",)
+
+    def __init__(self, n):
+        super().__init__([0] * n)
+        self.touched = set()
+
+    def __setitem__(self, i, v):
+        list.__setitem__(self, i, v)
+        if isinstance(i, int):
+            self.touched.add(i if i >= 0 else i + len(self))
+        else:                                   # a slice: forget the shortcut, column() scans
+            self.touched = None
+
+
 def _horner(coeffs, x):
     acc = 0
     for c in reversed(coeffs):
@@ -189,7 +206,7 @@ class ArithmeticCircuit(Circuit):
         return [int(v["constant"]), int(v["z"])]            # wasm.rs:93-94
 
     def synthesize_fixed(self, n):
-        cols = [[0] * n for _ in range(5)]
+        cols = [_Col(n) for _ in range(5)]
         for row in range(3):
             cols[self.SM][row] = cols[self.SO][row] = 1
         cols[self.SL][3] = cols[self.SR][3] = cols[self.SO][3] = 1
@@ -200,7 +217,7 @@ class ArithmeticCircuit(Circuit):
         xx, yy = x * x % P, y * y % P
         prod = xx * yy % P
         rows = [(x, x, xx), (y, y, yy), (xx, yy, prod), (prod, c, (prod + c) % P)]
-        cols = [[0] * n for _ in range(3)]
+        cols = [_Col(n) for _ in range(3)]
         for i, row in enumerate(rows):
             for j in range(3):
                 cols[j][i] = row[j]
@@ -360,7 +377,7 @@ class PoseidonCircuit(Circuit):
         return self._permutation_rows()[0][-1][0]
 
     def synthesize_advice(self, n):
-        adv = [[0] * n for _ in range(4)]
+        adv = [_Col(n) for _ in range(4)]
         m0, m1 = self.message
         cap = (2 << 64) % P
         adv[0][0], adv[1][0] = m0, m1
@@ -377,7 +394,7 @@ class PoseidonCircuit(Circuit):
         return adv
 
     def synthesize_fixed(self, n):
-        f = [[0] * n for _ in range(9)]
+        f = [_Col(n) for _ in range(9)]
         rcs = self.rcs
         f[3][2] = (2 << 64) % P
         f[8][3] = 1
@@ -440,7 +457,7 @@ class CollatzCircuit(Circuit):
         return []
 
     def synthesize_advice(self, n):
-        adv = [[0] * n for _ in range(3)]
+        adv = [_Col(n) for _ in range(3)]
         for i in range(31):
             row = i * (i + 3) // 2 + i
             adv[0][row], adv[0][row + 1] = self.x[i], self.x[i + 1]
@@ -450,7 +467,7 @@ class CollatzCircuit(Circuit):
         return adv
 
     def synthesize_fixed(self, n):
-        f = [[0] * n for _ in range(2)]
+        f = [_Col(n) for _ in range(2)]
         for i in range(31):
             f[1][i * (i + 3) // 2 + i] = 1
         f[0][527 + 31] = 1
@@ -606,7 +623,8 @@ class _Dev:
 
     def column(self, vals):
         """a length-n host column (list of canonical ints); sparse columns only convert their non-zero rows"""
-        rows = [i for i, v in enumerate(vals) if v]
+        touched = getattr(vals, "touched", None)
+        rows = sorted(i for i in touched if vals[i]) if touched is not None else [i for i, v in enumerate(vals) if v]
         if len(rows) * 8 > len(vals):
             return self.from_ints(vals)
         t = self.torch.zeros((len(vals), 4), dtype=self.torch.int64, device="cuda")
@@ -984,7 +1002,10 @@ def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
     tr.common_scalar(pk.transcript_repr)
     instance_cols = []
     if circuit.num_instance:
-        instance_cols = [dev.column([v % P for v in public_input] + [0] * (n - len(public_input)))]
+        inst = _Col(n)
+        for i, v in enumerate(public_input):
+            inst[i] = v % P
+        instance_cols = [dev.column(inst)]
         for v in public_input:
             tr.common_scalar(v)
     instance_values = torch.stack(instance_cols) if instance_cols else torch.zeros((0, n, 4), dtype=torch.int64, device="cuda")
@@ -1037,7 +1058,7 @@ def _create_proof(params, pk, circuit, public_input, rng, trace, opening):
     # coefficient forms (one batched inverse NTT on the GPU)
     basis = []
     for rows in ([0], [n - bf - 1], list(range(n - bf, n))):
-        v = [0] * n
+        v = _Col(n)
         for r in rows:
             v[r] = 1
         basis.append(dev.column(v))
