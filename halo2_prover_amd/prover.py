@@ -855,19 +855,28 @@ def generate_params(k, rng=None):
     g_dev = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     s_m = _limbs_of([s])
     _lib.check(L.h2_srs_generate(0, s_m.ctypes.data, n, ctypes.c_void_p(g_dev.data_ptr()), None), "h2_srs_generate")
-    # L_i(s) = w^i (s^n - 1) / (n (s - w^i))
+    # L_i(s) = w^i (s^n - 1) / (n (s - w^i)), all 2^k of them on the device: the column w^i (coset kernel on a column
+    # of ones), s - w^i, a per-element inversion, two pointwise products
     omega = pow(ROOT_OF_UNITY, 1 << (TWO_ADICITY - k), P)
-    w, ws = 1, []
-    for _ in range(n):
-        ws.append(w)
-        w = w * omega % P
-    if pow(s, n, P) == 1:                                    # s on the domain: L_i(s) is an indicator
-        lag = [1 if wi == s else 0 for wi in ws]
+    if pow(s, n, P) == 1:                                    # s on the domain: L_i(s) is an indicator (host, never hit)
+        lag = [1 if pow(omega, i, P) == s else 0 for i in range(n)]
+        sc_dev = torch.from_numpy(_limbs_of(lag).view(np.int64)).cuda()
     else:
+        def col_of(c):
+            return torch.from_numpy(_limbs_of([c]).view(np.int64)).cuda().expand(n, 4).contiguous()
+
+        def ptr(t):
+            return ctypes.c_void_p(t.data_ptr())
+
+        ws = col_of(1)
+        _lib.check(L.h2_poly_coset_device(0, ptr(ws), n, 1, _limbs_of([omega]).ctypes.data, None), "h2_poly_coset_device")
+        den = col_of(s)
+        _lib.check(L.h2_poly_pointwise_device(0, 1, ptr(den), ptr(ws), n, None), "h2_poly_pointwise_device")   # s - w^i
+        _lib.check(L.h2_poly_inverse_device(0, ptr(den), n, None), "h2_poly_inverse_device")
+        _lib.check(L.h2_poly_pointwise_device(0, 2, ptr(den), ptr(ws), n, None), "h2_poly_pointwise_device")   # w^i / (s - w^i)
         t = (pow(s, n, P) - 1) * pow(n, -1, P) % P
-        inv = _batch_inverse([(s - wi) % P for wi in ws])
-        lag = [wi * t % P * iv % P for wi, iv in zip(ws, inv)]
-    sc_dev = torch.from_numpy(_limbs_of(lag).view(np.int64)).cuda()
+        _lib.check(L.h2_poly_scale_device(0, ptr(den), n, 1, _limbs_of([t]).ctypes.data, None), "h2_poly_scale_device")
+        sc_dev = den
     gl_dev = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     _lib.check(L.h2_fixed_base_mul(0, ctypes.c_void_p(sc_dev.data_ptr()), n, ctypes.c_void_p(gl_dev.data_ptr()), None),
                "h2_fixed_base_mul")
