@@ -15,15 +15,19 @@
 //  * nbits+1 scalar bits are split into W windows of c or c-1 bits (balanced), so no window is
 //    degenerate; signed digits (|d| <= 2^(width-1)) halve the bucket count, the sign rides in
 //    bit 31 of the sorted entry and negates y on the fly.
-//  * sort by bucket: digits kernel (LDS histogram per block, one global atomic per block and
-//    bucket) -> exclusive scan -> scatter (LDS cursors), giving per bucket the contiguous list
-//    of table indices to add (4 bytes per entry; the entry's bucket is implied by `offsets`).
+//  * sort by bucket: count pass (LDS histogram per tile; its one returning global atomic per tile and bucket also
+//    hands the tile its base inside the bucket's list) -> exclusive scan -> scatter (LDS cursors), giving per
+//    bucket the contiguous list of table indices to add (4 bytes per entry; the entry's bucket is implied by
+//    `offsets`; both passes decompose the scalar themselves, no digits array is stored).
 //  * accumulate = segmented reduction with perfect load balance: every thread adds exactly T
 //    consecutive sorted entries (mixed XYZZ additions, 8M + 2S) whatever bucket they belong
 //    to, writes complete runs straight to the bucket and its cut-off head / tail runs to
-//    partial slots; a fix-up kernel sums each bucket's pieces with G lanes and a DPP shuffle
-//    tree (buckets cut into hundreds of pieces -- degenerate columns -- first go through a
-//    wave-per-128-pieces reduction), then the bucket weights (b+1) and a two-level tree sum.
+//    partial slots; a fix-up kernel sums each bucket's pieces (buckets cut into hundreds of pieces --
+//    degenerate columns -- first go through a wave-per-128-pieces reduction), then the bucket weights (b+1) and a
+//    two-level tree sum.  Fix-up, weights and tree run with FOUR LANES PER POINT (h2_curve_quad.hpp).
+//  * all base-field arithmetic of these kernels is done on 9 x 29-bit signed limbs with lazy reduction
+//    (h2_field29.hpp, h2_curve29.hpp); the table holds the points in that Montgomery form (R' = 2^261) and the m
+//    results are converted back to the API's form by the final kernel.
 #pragma once
 #include "h2_curve29.hpp"
 #include "h2_curve_quad.hpp"
