@@ -135,6 +135,27 @@ class Bases:
         _lib.check(st, "h2_msm_device")
 
 
+    def msm_device_range(self, d_scalars, first_base, n, col_stride, m, d_out_jac, stream=0):
+        """m columns (col_stride elements apart) against bases[first_base : first_base + n] -> m Jacobian points"""
+        st = _lib.load().h2_msm_device_range(self.curve, self.handle, ctypes.c_void_p(d_scalars), first_base, n,
+                                             col_stride, m, ctypes.c_void_p(d_out_jac), ctypes.c_void_p(stream))
+        _lib.check(st, "h2_msm_device_range")
+
+    def points_sum_device(self, d_in_jac, groups, count, d_out_jac, stream=0):
+        """out[j] = sum_g in[g * count + j]: adds the all-gathered partial sums of a range-split MSM"""
+        st = _lib.load().h2_points_sum_device(self.curve, ctypes.c_void_p(d_in_jac), groups, count,
+                                              ctypes.c_void_p(d_out_jac), ctypes.c_void_p(stream))
+        _lib.check(st, "h2_points_sum_device")
+
+
+def init_devices(device_ids):
+    """One process, several GPUs (h2_init_devices): host-pointer batches are then sharded over the devices."""
+    global _initialised
+    ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+    _lib.check(_lib.load().h2_init_devices(len(device_ids), ids), "h2_init_devices")
+    _initialised = True
+
+
 def best_multiexp(coeffs, bases, curve="bn254"):
     """best_multiexp(coeffs, bases) -> Jacobian point (12 limbs).  One-shot form: registers the
     bases, runs the MSM and releases them (use `Bases` / `ParamsKZG` to keep an SRS resident)."""
@@ -217,9 +238,11 @@ class ParamsKZG:
         if len(data) < 4:
             raise ValueError("ParamsKZG.read: truncated")
         k = int.from_bytes(data[:4], "little")
+        if k > 28:
+            raise ValueError("ParamsKZG.read: k=%d out of range" % k)
         n = 1 << k
         need = 4 + 128 * n + 256
-        if k > 28 or len(data) != need:
+        if len(data) != need:
             raise ValueError("ParamsKZG.read: expected %d bytes for k=%d, got %d" % (need, k, len(data)))
         g = np.frombuffer(data, dtype=np.uint64, count=8 * n, offset=4).reshape(n, 8).copy()
         gl = np.frombuffer(data, dtype=np.uint64, count=8 * n, offset=4 + 64 * n).reshape(n, 8).copy()

@@ -5,95 +5,26 @@
 // errors as h2_status_t values: nothing throws or aborts across the ABI
 // (the reference's panics -- /root/reference/circuits/src/utils.rs:91,120 `.expect(..)`,
 // best_multiexp's assert_eq!(coeffs.len(), bases.len()) -- become H2_EINVAL here).
-#include "../../include/h2hip.h"
+#include "h2_internal.hpp"
 
 #include <cstdio>
 #include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
 
-#include "h2_curve_ops.hpp"
-#include "h2_msm.hpp"
 #include "h2_ntt.hpp"
 #include "h2_poly.hpp"
 
 using namespace h2;
 
-namespace {
+namespace h2 {
 
-struct BasesEntry {
-  int curve;
-  size_t n;
-  MsmGeom geom;
-  void* table;  // W * n affine points
-  size_t table_bytes;
-};
-
-struct TwiddleEntry {
-  int field;
-  uint32_t log_n;
-  uint64_t omega[4];
-  void* tw;
-  uint64_t stamp;
-};
-
-struct Context {
-  bool ready = false;
-  int device = -1;
-  hipStream_t stream = nullptr;
-  void* ws = nullptr;       // workspace arena (MSM scratch / NTT ping-pong)
-  size_t ws_bytes = 0;
-  void* stage = nullptr;    // device staging for host-pointer entry points
-  size_t stage_bytes = 0;
-  void* div_ws = nullptr;   // chunk values of h2_poly_divide_linear_device (2 * 1024 elements)
-  std::map<uint64_t, BasesEntry> bases;
-  uint64_t next_handle = 1;
-  std::vector<TwiddleEntry> twiddles;
-  uint64_t stamp = 0;
-  // kernel timing for the roofline (h2_profile_*): event pairs around the bucket-accumulate kernel
-  bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  size_t prof_used = 0;
-  double prof_alg_bytes = 0;
-  std::string last_error;
-};
-
-Context g_ctx;
-std::mutex g_mu;
+Global g_h2;
+std::recursive_mutex g_h2_mu;
 
 int dev_fail(hipError_t e, const char* where) {
   char buf[256];
   snprintf(buf, sizeof buf, "%s: %s", where, hipGetErrorString(e));
-  g_ctx.last_error = buf;
+  g_h2.last_error = buf;
   return H2_EDEVICE;
-}
-#define H2_TRY(call)                                  \
-  do {                                                \
-    hipError_t _e = (call);                           \
-    if (_e != hipSuccess) return dev_fail(_e, #call); \
-  } while (0)
-
-int ensure_arena(void** p, size_t* have, size_t want) {
-  if (*have >= want) return H2_OK;
-  if (*p) {
-    // rare: a larger call than any before.  Work enqueued on caller streams may still use the arena.
-    hipError_t e = hipDeviceSynchronize();
-    if (e != hipSuccess) return dev_fail(e, "hipDeviceSynchronize");
-    (void)hipFree(*p);
-    *p = nullptr;
-    *have = 0;
-  }
-  size_t sz = want + (want >> 3);  // head-room so slightly larger calls do not reallocate
-  hipError_t e = hipMalloc(p, sz);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    g_ctx.last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
-    return H2_ENOMEM;
-  }
-  *have = sz;
-  return H2_OK;
 }
 
 bool curve_ok(int c) { return c == H2_BN254 || c == H2_PALLAS || c == H2_VESTA; }
@@ -107,9 +38,56 @@ const CurveOps* ops_of(int curve) {
   return nullptr;
 }
 
+DevCtx* ctx_current() {
+  if (!g_h2.ready || g_h2.ctx.empty()) return nullptr;
+  if (g_h2.ctx.size() == 1) return &g_h2.ctx[0];
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (auto& c : g_h2.ctx)
+    if (c.device == dev) return &c;
+  return nullptr;
+}
+size_t ctx_index(const DevCtx* c) { return (size_t)(c - &g_h2.ctx[0]); }
+
+// ---- arenas ----------------------------------------------------------------------------------
+int arena_acquire(Arena& a, size_t want, hipStream_t s) {
+  if (a.bytes < want) {
+    if (a.p) {
+      // rare: a larger call than any before.  Work enqueued on other streams may still use the arena.
+      H2_TRY(hipDeviceSynchronize());
+      (void)hipFree(a.p);
+      a.p = nullptr;
+      a.bytes = 0;
+      a.used = false;
+    }
+    const size_t sz = want + (want >> 3);  // head-room so slightly larger calls do not reallocate
+    hipError_t e = hipMalloc(&a.p, sz);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      g_h2.last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+      return H2_ENOMEM;
+    }
+    a.bytes = sz;
+  }
+  if (!a.ev) H2_TRY(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
+  if (a.used && a.last != s) H2_TRY(hipStreamWaitEvent(s, a.ev, 0));   // order behind the previous user
+  return H2_OK;
+}
+int arena_release(Arena& a, hipStream_t s) {
+  H2_TRY(hipEventRecord(a.ev, s));
+  a.last = s;
+  a.used = true;
+  return H2_OK;
+}
+static void arena_free(Arena& a) {
+  if (a.p) (void)hipFree(a.p);
+  if (a.ev) (void)hipEventDestroy(a.ev);
+  a = Arena{};
+}
+
 // ---- bases ---------------------------------------------------------------------------------
-int register_device(int curve, const void* d_affine, size_t n, uint64_t* handle_out) {
-  if (!g_ctx.ready) return H2_ENOTINIT;
+// d_affine lives on context `src`; the table is built there and copied to every other context
+static int register_device(DevCtx& src, int curve, const void* d_affine, size_t n, uint64_t* handle_out) {
   if (!curve_ok(curve) || !d_affine || !handle_out || n == 0) return H2_EINVAL;
   const CurveOps* ops = ops_of(curve);
   MsmGeom g = msm_geometry(n, ops->scalar_bits);
@@ -119,80 +97,121 @@ int register_device(int curve, const void* d_affine, size_t n, uint64_t* handle_
   be.n = n;
   be.geom = g;
   be.table_bytes = (size_t)g.W * n * 64;
-  hipError_t e = hipMalloc(&be.table, be.table_bytes);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    g_ctx.last_error = std::string("hipMalloc(table): ") + hipGetErrorString(e);
-    return H2_ENOMEM;
+  be.table.assign(g_h2.ctx.size(), nullptr);
+  auto fail = [&](int rc) {
+    for (size_t i = 0; i < be.table.size(); i++)
+      if (be.table[i]) {
+        DeviceGuard dg(g_h2.ctx[i].device);
+        (void)hipFree(be.table[i]);
+      }
+    return rc;
+  };
+  for (size_t i = 0; i < g_h2.ctx.size(); i++) {
+    DeviceGuard dg(g_h2.ctx[i].device);
+    hipError_t e = hipMalloc(&be.table[i], be.table_bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      be.table[i] = nullptr;
+      g_h2.last_error = std::string("hipMalloc(table): ") + hipGetErrorString(e);
+      return fail(H2_ENOMEM);
+    }
   }
-  e = ops->table_build(d_affine, be.table, (uint32_t)n, g, g_ctx.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
-  if (e != hipSuccess) {
-    (void)hipFree(be.table);
-    return dev_fail(e, "msm_table_kernel");
+  const size_t si = ctx_index(&src);
+  {
+    DeviceGuard dg(src.device);
+    hipError_t e = ops->table_build(d_affine, be.table[si], (uint32_t)n, g, src.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(src.stream);
+    if (e != hipSuccess) return fail(dev_fail(e, "msm_table_kernel"));
+    for (size_t i = 0; i < g_h2.ctx.size(); i++) {
+      if (i == si) continue;
+      e = hipMemcpyPeer(be.table[i], g_h2.ctx[i].device, be.table[si], src.device, be.table_bytes);
+      if (e != hipSuccess) return fail(dev_fail(e, "hipMemcpyPeer(table)"));
+    }
   }
-  uint64_t h = g_ctx.next_handle++;
-  g_ctx.bases[h] = be;
+  uint64_t h = g_h2.next_handle++;
+  g_h2.bases[h] = be;
   *handle_out = h;
   return H2_OK;
 }
 
 // ---- MSM -----------------------------------------------------------------------------------
-// enqueue; the m XYZZ results land at ws + off_tree2
-int msm_enqueue(int curve, const BasesEntry& be, const void* d_scalars, size_t n, size_t m, hipStream_t stream,
-                MsmWorkspace* ws_out) {
-  MsmWorkspace ws = msm_workspace(n, m, be.geom);
-  if (ws.E >= (1ull << 31) || ws.K >= (1ull << 31)) return H2_EINVAL;
-  int rc = ensure_arena(&g_ctx.ws, &g_ctx.ws_bytes, ws.total);
-  if (rc != H2_OK) return rc;
-  *ws_out = ws;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (g_ctx.profiling) {
-    if (g_ctx.prof_used == g_ctx.prof_events.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) g_ctx.prof_events.push_back({a, b});
-    }
-    if (g_ctx.prof_used < g_ctx.prof_events.size()) {
-      ev0 = g_ctx.prof_events[g_ctx.prof_used].first;
-      ev1 = g_ctx.prof_events[g_ctx.prof_used].second;
-      g_ctx.prof_used++;
-      g_ctx.prof_alg_bytes += (double)m * (double)n * 96.0 + (double)m * 96.0;  // SURVEY.md 8(d) bytes_msm
-    }
-  }
-  hipError_t e = ops_of(curve)->msm_launch(be.table, (uint32_t)be.n, d_scalars, n, m, be.geom, (char*)g_ctx.ws, ws,
-                                          stream, ev0, ev1);
-  if (e != hipSuccess) return dev_fail(e, "msm_launch");
-  return H2_OK;
-}
-
-int msm_common_checks(int curve, uint64_t handle, size_t n, size_t m, const BasesEntry** be) {
-  if (!g_ctx.ready) return H2_ENOTINIT;
+int msm_common_checks(int curve, uint64_t handle, size_t first, size_t n, size_t m, const BasesEntry** be) {
+  if (!g_h2.ready) return H2_ENOTINIT;
   if (!curve_ok(curve) || m == 0) return H2_EINVAL;
-  auto it = g_ctx.bases.find(handle);
-  if (it == g_ctx.bases.end()) return H2_EHANDLE;
+  auto it = g_h2.bases.find(handle);
+  if (it == g_h2.bases.end()) return H2_EHANDLE;
   if (it->second.curve != curve) return H2_EINVAL;
-  if (n > it->second.n) return H2_EINVAL;  // best_multiexp: assert_eq!(coeffs.len(), bases.len())
+  if (first > it->second.n || n > it->second.n - first) return H2_EINVAL;  // best_multiexp: assert_eq!(coeffs.len(), bases.len())
   *be = &it->second;
   return H2_OK;
 }
 
+// Columns per launch: the sort indexes its m * W * n entries with 32 bits, so a wide batch of long columns
+// (2^24 rows x 8 columns) goes through in groups of columns, one after the other on the same stream and workspace.
+static uint64_t g_msm_max_entries = (1ull << 31) - 1;   // lowered only by h2_selftest_set_msm_max_entries (tests)
+static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
+  const uint64_t per_col = (uint64_t)be.geom.W * n;
+  const uint64_t by_entries = g_msm_max_entries / per_col;
+  const uint64_t by_keys = ((1ull << 31) - 1) / be.geom.B;
+  return (size_t)(by_entries < by_keys ? by_entries : by_keys);   // 0: a single column is already too long
+}
+
+int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_scalars, size_t first_base, size_t n,
+                   size_t col_stride, size_t m, void* d_out, bool affine_out, hipStream_t stream) {
+  const size_t group = msm_cols_per_launch(be, n);
+  if (group == 0) return H2_EINVAL;
+  const size_t out_sz = affine_out ? 64 : 96;
+  const CurveOps* ops = ops_of(curve);
+  // the table rows of bases first_base ...: entries are w * n_bases + i relative to this pointer
+  const char* table = (const char*)be.table[ctx_index(&c)] + first_base * 64;
+  for (size_t j0 = 0; j0 < m; j0 += group) {
+    const size_t mm = m - j0 < group ? m - j0 : group;
+    MsmWorkspace ws = msm_workspace(n, mm, be.geom);
+    if (ws.E >= (1ull << 31) || ws.K >= (1ull << 31)) return H2_EINVAL;
+    int rc = arena_acquire(c.msm_ws, ws.total, stream);
+    if (rc != H2_OK) return rc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_h2.profiling) {
+      if (c.prof_used == c.prof_events.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) c.prof_events.push_back({a, b});
+      }
+      if (c.prof_used < c.prof_events.size()) {
+        ev0 = c.prof_events[c.prof_used].first;
+        ev1 = c.prof_events[c.prof_used].second;
+        c.prof_used++;
+        c.prof_alg_bytes += (double)mm * (double)n * 96.0 + (double)mm * 96.0;  // SURVEY.md 8(d) bytes_msm
+      }
+    }
+    hipError_t e = ops->msm_launch(table, (uint32_t)be.n, (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
+                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1);
+    if (e != hipSuccess) return dev_fail(e, "msm_launch");
+    const void* src = (char*)c.msm_ws.p + ws.off_tree2;
+    void* dst = (char*)d_out + j0 * out_sz;
+    e = affine_out ? ops->to_affine(src, dst, (uint32_t)mm, stream) : ops->to_jacobian(src, dst, (uint32_t)mm, stream);
+    if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
+    rc = arena_release(c.msm_ws, stream);
+    if (rc != H2_OK) return rc;
+  }
+  return H2_OK;
+}
+
 // ---- NTT -----------------------------------------------------------------------------------
-int get_twiddles(const CurveOps* ops, const uint64_t omega[4], uint32_t log_n, hipStream_t stream,
-                 const void** out) {
-  for (auto& t : g_ctx.twiddles) {
+static int get_twiddles(DevCtx& c, const CurveOps* ops, const uint64_t omega[4], uint32_t log_n, const void** out) {
+  for (auto& t : c.twiddles) {
     if (t.field == ops->scalar_field_id && t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) {
-      t.stamp = ++g_ctx.stamp;
+      t.stamp = ++c.stamp;
       *out = t.tw;
       return H2_OK;
     }
   }
-  if (g_ctx.twiddles.size() >= 16) {  // evict the least recently used table
+  if (c.twiddles.size() >= 16) {  // evict the least recently used table
     size_t victim = 0;
-    for (size_t i = 1; i < g_ctx.twiddles.size(); i++)
-      if (g_ctx.twiddles[i].stamp < g_ctx.twiddles[victim].stamp) victim = i;
+    for (size_t i = 1; i < c.twiddles.size(); i++)
+      if (c.twiddles[i].stamp < c.twiddles[victim].stamp) victim = i;
     H2_TRY(hipDeviceSynchronize());
-    (void)hipFree(g_ctx.twiddles[victim].tw);
-    g_ctx.twiddles.erase(g_ctx.twiddles.begin() + victim);
+    (void)hipFree(c.twiddles[victim].tw);
+    c.twiddles.erase(c.twiddles.begin() + victim);
   }
   TwiddleEntry te{};
   te.field = ops->scalar_field_id;
@@ -204,33 +223,88 @@ int get_twiddles(const CurveOps* ops, const uint64_t omega[4], uint32_t log_n, h
     (void)hipGetLastError();
     return H2_ENOMEM;
   }
-  e = ops->ntt_twiddles(te.tw, omega, log_n, stream);
+  // built on the library's stream and finished before anybody uses it: a table is shared by every later caller,
+  // whatever stream they bring (once per (field, omega, log n))
+  e = ops->ntt_twiddles(te.tw, omega, log_n, c.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
   if (e != hipSuccess) {
     (void)hipFree(te.tw);
     return dev_fail(e, "ntt_build_twiddles");
   }
-  te.stamp = ++g_ctx.stamp;
-  g_ctx.twiddles.push_back(te);
+  te.stamp = ++c.stamp;
+  c.twiddles.push_back(te);
   *out = te.tw;
   return H2_OK;
 }
 
-int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream,
-                const uint64_t* scale = nullptr) {
+int ntt_enqueue(DevCtx& c, int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream,
+                const uint64_t* scale) {
   const CurveOps* ops = ops_of(curve);
   if (!ops) return H2_EINVAL;
   const void* tw = nullptr;
-  int rc = get_twiddles(ops, omega, log_n, stream, &tw);
+  int rc = get_twiddles(c, ops, omega, log_n, &tw);
   if (rc != H2_OK) return rc;
   NttPlan pl = ntt_make_plan(log_n);
   void* scratch = nullptr;
   if (pl.npass > 1) {
-    rc = ensure_arena(&g_ctx.ws, &g_ctx.ws_bytes, m * ((size_t)32 << log_n));
+    rc = arena_acquire(c.ntt_ws, m * ((size_t)32 << log_n), stream);
     if (rc != H2_OK) return rc;
-    scratch = g_ctx.ws;
+    scratch = c.ntt_ws.p;
   }
   hipError_t e = ops->ntt_launch(d_a, scratch, tw, log_n, m, stream, scale);
   if (e != hipSuccess) return dev_fail(e, "ntt_launch");
+  if (pl.npass > 1) return arena_release(c.ntt_ws, stream);
+  return H2_OK;
+}
+
+}  // namespace h2
+
+namespace {
+
+// every *_device entry point: the context of the current device, and the stream the work goes to
+struct Call {
+  DevCtx* c = nullptr;
+  hipStream_t stream = nullptr;
+  int rc = H2_OK;
+  Call(void* stream_) {
+    if (!g_h2.ready) { rc = H2_ENOTINIT; return; }
+    c = ctx_current();
+    if (!c) { rc = H2_EINVAL; g_h2.last_error = "no h2 context on the current HIP device"; return; }
+    stream = stream_ ? (hipStream_t)stream_ : c->stream;
+  }
+};
+
+int init_devices(int n, const int* ids) {
+  if (g_h2.ready) {
+    if ((size_t)n != g_h2.ctx.size()) return H2_EINVAL;
+    for (int i = 0; i < n; i++)
+      if (g_h2.ctx[i].device != ids[i]) return H2_EINVAL;
+    return H2_OK;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    (void)hipGetLastError();
+    g_h2.last_error = "no HIP device available";
+    return H2_EDEVICE;
+  }
+  for (int i = 0; i < n; i++)
+    if (ids[i] < 0 || ids[i] >= count) return H2_EINVAL;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  g_h2.ctx.assign((size_t)n, DevCtx{});
+  for (int i = 0; i < n; i++) {
+    DevCtx& c = g_h2.ctx[i];
+    c.device = ids[i];
+    H2_TRY(hipSetDevice(ids[i]));
+    // a BLOCKING stream on purpose: callers that pass stream = NULL (e.g. PyTorch's legacy default stream)
+    // get work that is ordered against the null stream, so their own copies / kernels see finished results
+    H2_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamDefault));
+    for (int cv = 0; cv < 3; cv++) H2_TRY(ops_of(cv)->kernel_setup());
+  }
+  // one context: stay on its device (h2_init(device) has always left the process there); several: back to where we were
+  H2_TRY(hipSetDevice(n == 1 ? ids[0] : prev));
+  g_h2.ready = true;
   return H2_OK;
 }
 
@@ -238,7 +312,7 @@ int ntt_enqueue(int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_
 
 extern "C" {
 
-int h2_version(void) { return 1000; }
+int h2_version(void) { return 1001; }
 
 const char* h2_strerror(int s) {
   switch (s) {
@@ -248,97 +322,110 @@ const char* h2_strerror(int s) {
     case H2_EDEVICE: return "HIP device error";
     case H2_EHANDLE: return "unknown bases handle";
     case H2_ENOTINIT: return "h2_init has not been called";
+    case H2_EPROOF: return "proof or input rejected";
   }
   return "unknown status";
 }
 
 const char* h2_last_device_error(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   static thread_local std::string copy;
-  copy = g_ctx.last_error;
+  copy = g_h2.last_error;
   return copy.c_str();
 }
 
 int h2_init(int device) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_ctx.ready) return g_ctx.device == device ? H2_OK : H2_EINVAL;
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count == 0) {
-    (void)hipGetLastError();
-    g_ctx.last_error = "no HIP device available";
-    return H2_EDEVICE;
-  }
-  if (device < 0 || device >= count) return H2_EINVAL;
-  H2_TRY(hipSetDevice(device));
-  // a BLOCKING stream on purpose: callers that pass stream = NULL (e.g. PyTorch's legacy default stream)
-  // get work that is ordered against the null stream, so their own copies / kernels see finished results
-  H2_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamDefault));
-  g_ctx.device = device;
-  g_ctx.ready = true;
-  return H2_OK;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  return init_devices(1, &device);
+}
+
+int h2_init_devices(int n_devices, const int* device_ids) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (n_devices <= 0 || n_devices > 64 || !device_ids) return H2_EINVAL;
+  return init_devices(n_devices, device_ids);
+}
+
+int h2_device_count(void) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  return g_h2.ready ? (int)g_h2.ctx.size() : H2_ENOTINIT;
 }
 
 int h2_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_OK;
-  (void)hipStreamSynchronize(g_ctx.stream);
-  for (auto& kv : g_ctx.bases) (void)hipFree(kv.second.table);
-  g_ctx.bases.clear();
-  for (auto& t : g_ctx.twiddles) (void)hipFree(t.tw);
-  g_ctx.twiddles.clear();
-  if (g_ctx.ws) (void)hipFree(g_ctx.ws);
-  if (g_ctx.stage) (void)hipFree(g_ctx.stage);
-  if (g_ctx.div_ws) (void)hipFree(g_ctx.div_ws);
-  g_ctx.ws = g_ctx.stage = g_ctx.div_ws = nullptr;
-  g_ctx.ws_bytes = g_ctx.stage_bytes = 0;
-  (void)hipStreamDestroy(g_ctx.stream);
-  g_ctx.stream = nullptr;
-  g_ctx.ready = false;
-  g_ctx.device = -1;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_OK;
+  for (size_t i = 0; i < g_h2.ctx.size(); i++) {
+    DevCtx& c = g_h2.ctx[i];
+    DeviceGuard dg(c.device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : g_h2.bases)
+      if (kv.second.table[i]) (void)hipFree(kv.second.table[i]);
+    for (auto& t : c.twiddles) (void)hipFree(t.tw);
+    arena_free(c.msm_ws);
+    arena_free(c.ntt_ws);
+    arena_free(c.stage);
+    arena_free(c.div_ws);
+    for (auto& pe : c.prof_events) {
+      (void)hipEventDestroy(pe.first);
+      (void)hipEventDestroy(pe.second);
+    }
+    (void)hipStreamDestroy(c.stream);
+  }
+  g_h2.bases.clear();
+  g_h2.ctx.clear();
+  g_h2.ready = false;
   return H2_OK;
 }
 
 int h2_bases_register_device(h2_curve_t curve, const void* d_affine, size_t n, uint64_t* handle_out) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  return register_device((int)curve, d_affine, n, handle_out);
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(nullptr);
+  if (k.rc != H2_OK) return k.rc;
+  // the caller's copy / kernel that produced d_affine may still be in flight on another stream
+  H2_TRY(hipDeviceSynchronize());
+  return register_device(*k.c, (int)curve, d_affine, n, handle_out);
 }
 
 int h2_bases_register(h2_curve_t curve, const uint64_t* affine, size_t n, uint64_t* handle_out) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
   if (!curve_ok((int)curve) || !affine || !handle_out || n == 0) return H2_EINVAL;
-  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, n * 64);
+  DevCtx& c = g_h2.ctx[0];
+  DeviceGuard dg(c.device);
+  int rc = arena_acquire(c.stage, n * 64, c.stream);
   if (rc != H2_OK) return rc;
-  H2_TRY(hipMemcpyAsync(g_ctx.stage, affine, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
-  return register_device((int)curve, g_ctx.stage, n, handle_out);
+  H2_TRY(hipMemcpyAsync(c.stage.p, affine, n * 64, hipMemcpyHostToDevice, c.stream));
+  rc = register_device(c, (int)curve, c.stage.p, n, handle_out);   // synchronises c.stream
+  return rc;
 }
 
 int h2_bases_release(uint64_t handle) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
-  auto it = g_ctx.bases.find(handle);
-  if (it == g_ctx.bases.end()) return H2_EHANDLE;
-  (void)hipStreamSynchronize(g_ctx.stream);
-  (void)hipFree(it->second.table);
-  g_ctx.bases.erase(it);
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
+  auto it = g_h2.bases.find(handle);
+  if (it == g_h2.bases.end()) return H2_EHANDLE;
+  for (size_t i = 0; i < g_h2.ctx.size(); i++) {
+    DeviceGuard dg(g_h2.ctx[i].device);
+    (void)hipDeviceSynchronize();     // launches on caller streams may still read the table
+    (void)hipFree(it->second.table[i]);
+  }
+  g_h2.bases.erase(it);
   return H2_OK;
 }
 
 int64_t h2_bases_len(uint64_t handle) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
-  auto it = g_ctx.bases.find(handle);
-  if (it == g_ctx.bases.end()) return H2_EHANDLE;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
+  auto it = g_h2.bases.find(handle);
+  if (it == g_h2.bases.end()) return H2_EHANDLE;
   return (int64_t)it->second.n;
 }
 
 int h2_msm_plan(uint64_t handle, h2_msm_plan_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
   if (!out) return H2_EINVAL;
-  auto it = g_ctx.bases.find(handle);
-  if (it == g_ctx.bases.end()) return H2_EHANDLE;
+  auto it = g_h2.bases.find(handle);
+  if (it == g_h2.bases.end()) return H2_EHANDLE;
   out->window_bits = it->second.geom.c;
   out->windows = it->second.geom.W;
   out->buckets = it->second.geom.B;
@@ -346,61 +433,47 @@ int h2_msm_plan(uint64_t handle, h2_msm_plan_t* out) {
   return H2_OK;
 }
 
-// Columns per launch: the sort indexes its m * W * n entries with 32 bits, so a wide batch of long columns
-// (2^24 rows x 8 columns) goes through in groups of columns, one after the other on the same stream and workspace.
-// H2_MSM_MAX_ENTRIES lowers the limit (tests use it to reach the grouped path at small sizes).
-static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
-  uint64_t limit = (1ull << 31) - 1;
-  if (const char* ov = getenv("H2_MSM_MAX_ENTRIES")) {
-    const uint64_t v = strtoull(ov, nullptr, 10);
-    if (v > 0 && v < limit) limit = v;
+int h2_msm_device_range(h2_curve_t curve, uint64_t handle, const void* d_scalars, size_t first_base, size_t n,
+                        size_t col_stride, size_t m, void* d_out_jac, void* stream_) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  const BasesEntry* be = nullptr;
+  int rc = msm_common_checks((int)curve, handle, first_base, n, m, &be);
+  if (rc != H2_OK) return rc;
+  if (!d_out_jac || (n && !d_scalars) || (m > 1 && col_stride < n)) return H2_EINVAL;
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
+  if (n == 0) {
+    H2_TRY(hipMemsetAsync(d_out_jac, 0, m * 96, k.stream));
+    return H2_OK;
   }
-  const uint64_t per_col = (uint64_t)be.geom.W * n;
-  uint64_t by_entries = limit / per_col;
-  const uint64_t by_keys = ((1ull << 31) - 1) / be.geom.B;
-  return (size_t)(by_entries < by_keys ? by_entries : by_keys);   // 0: a single column is already too long
-}
-
-// m columns at d_scalars (column stride n) -> m results at d_out (96-byte Jacobian or 64-byte affine), enqueued
-static int msm_device_run(int curve, const BasesEntry& be, const void* d_scalars, size_t n, size_t m, void* d_out,
-                          bool affine_out, hipStream_t stream) {
-  const size_t group = msm_cols_per_launch(be, n);
-  if (group == 0) return H2_EINVAL;
-  const size_t out_sz = affine_out ? 64 : 96;
-  const CurveOps* ops = ops_of(curve);
-  for (size_t j0 = 0; j0 < m; j0 += group) {
-    const size_t mm = m - j0 < group ? m - j0 : group;
-    MsmWorkspace ws;
-    int rc = msm_enqueue(curve, be, (const char*)d_scalars + j0 * n * 32, n, mm, stream, &ws);
-    if (rc != H2_OK) return rc;
-    const void* src = (char*)g_ctx.ws + ws.off_tree2;
-    void* dst = (char*)d_out + j0 * out_sz;
-    hipError_t e = affine_out ? ops->to_affine(src, dst, (uint32_t)mm, stream)
-                              : ops->to_jacobian(src, dst, (uint32_t)mm, stream);
-    if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
-  }
-  return H2_OK;
+  return msm_device_run(*k.c, (int)curve, *be, d_scalars, first_base, n, col_stride, m, d_out_jac, false, k.stream);
 }
 
 int h2_msm_device(h2_curve_t curve, uint64_t handle, const void* d_scalars, size_t n, size_t m, void* d_out_jac,
                   void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  const BasesEntry* be = nullptr;
-  int rc = msm_common_checks((int)curve, handle, n, m, &be);
-  if (rc != H2_OK) return rc;
-  if (!d_out_jac || (n && !d_scalars)) return H2_EINVAL;
-  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
-  if (n == 0) {
-    H2_TRY(hipMemsetAsync(d_out_jac, 0, m * 96, stream));
-    return H2_OK;
-  }
-  return msm_device_run((int)curve, *be, d_scalars, n, m, d_out_jac, false, stream);
+  return h2_msm_device_range(curve, handle, d_scalars, 0, n, n, m, d_out_jac, stream_);
 }
 
+int h2_points_sum_device(h2_curve_t curve, const void* d_in_jac, size_t groups, size_t count, void* d_out_jac,
+                         void* stream_) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
+  if (!curve_ok((int)curve) || !d_in_jac || !d_out_jac || groups == 0 || groups > (1u << 20) || count > (1u << 24))
+    return H2_EINVAL;
+  if (count == 0) return H2_OK;
+  hipError_t e = ops_of((int)curve)->points_sum(d_in_jac, d_out_jac, (uint32_t)groups, (uint32_t)count, k.stream);
+  if (e != hipSuccess) return dev_fail(e, "points_sum_kernel");
+  return H2_OK;
+}
+
+// Host-pointer MSMs.  With several contexts (h2_init_devices) a batch is sharded by column, column j -> context
+// j mod G, and a single long MSM by contiguous point range with the G partial sums added on context 0
+// (SURVEY.md section 8(e)); every context works on its own stream, the host waits once at the end.
 static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* cols, size_t n, size_t m, uint64_t* out,
                     bool affine_out) {
   const BasesEntry* be = nullptr;
-  int rc = msm_common_checks((int)curve, handle, n, m, &be);
+  int rc = msm_common_checks((int)curve, handle, 0, n, m, &be);
   if (rc != H2_OK) return rc;
   if (!out || !cols) return H2_EINVAL;
   const size_t out_sz = affine_out ? 64 : 96;
@@ -410,23 +483,70 @@ static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* co
   }
   for (size_t j = 0; j < m; j++)
     if (!cols[j]) return H2_EINVAL;
+  const size_t G = g_h2.ctx.size();
   const size_t col_bytes = n * 32;
-  const size_t res_off = h2_align256(m * col_bytes);
-  rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, res_off + m * 96);
-  if (rc != H2_OK) return rc;
-  for (size_t j = 0; j < m; j++)
-    H2_TRY(hipMemcpyAsync((char*)g_ctx.stage + j * col_bytes, cols[j], col_bytes, hipMemcpyHostToDevice,
-                          g_ctx.stream));
-  void* d_res = (char*)g_ctx.stage + res_off;
-  rc = msm_device_run((int)curve, *be, g_ctx.stage, n, m, d_res, affine_out, g_ctx.stream);
-  if (rc != H2_OK) return rc;
-  H2_TRY(hipMemcpyAsync(out, d_res, m * out_sz, hipMemcpyDeviceToHost, g_ctx.stream));
-  H2_TRY(hipStreamSynchronize(g_ctx.stream));
+  if (m == 1 && G > 1 && n >= 4096 * G) {
+    // point-range split of one MSM: context g takes bases [lo_g, hi_g)
+    std::vector<uint64_t> partial(G * 12);
+    for (size_t g = 0; g < G; g++) {
+      DevCtx& c = g_h2.ctx[g];
+      DeviceGuard dg(c.device);
+      const size_t lo = n * g / G, hi = n * (g + 1) / G, cnt = hi - lo;
+      const size_t res_off = h2_align256(cnt * 32);
+      rc = arena_acquire(c.stage, res_off + 96, c.stream);
+      if (rc != H2_OK) return rc;
+      H2_TRY(hipMemcpyAsync(c.stage.p, (const char*)cols[0] + lo * 32, cnt * 32, hipMemcpyHostToDevice, c.stream));
+      void* d_res = (char*)c.stage.p + res_off;
+      rc = msm_device_run(c, (int)curve, *be, c.stage.p, lo, cnt, cnt, 1, d_res, false, c.stream);
+      if (rc != H2_OK) return rc;
+      H2_TRY(hipMemcpyAsync(&partial[12 * g], d_res, 96, hipMemcpyDeviceToHost, c.stream));
+    }
+    for (size_t g = 0; g < G; g++) {
+      DeviceGuard dg(g_h2.ctx[g].device);
+      H2_TRY(hipStreamSynchronize(g_h2.ctx[g].stream));
+    }
+    // add the G partial sums on context 0 (they are 96 bytes each)
+    DevCtx& c = g_h2.ctx[0];
+    DeviceGuard dg(c.device);
+    const size_t res_off = h2_align256(G * 96);
+    rc = arena_acquire(c.stage, res_off + 96, c.stream);
+    if (rc != H2_OK) return rc;
+    H2_TRY(hipMemcpyAsync(c.stage.p, partial.data(), G * 96, hipMemcpyHostToDevice, c.stream));
+    void* d_res = (char*)c.stage.p + res_off;
+    hipError_t e = ops_of((int)curve)->points_sum(c.stage.p, d_res, (uint32_t)G, 1, c.stream);
+    if (e != hipSuccess) return dev_fail(e, "points_sum_kernel");
+    if (affine_out) return H2_EINVAL;   // not reached: h2_msm asks for Jacobian
+    H2_TRY(hipMemcpyAsync(out, d_res, 96, hipMemcpyDeviceToHost, c.stream));
+    H2_TRY(hipStreamSynchronize(c.stream));
+    return H2_OK;
+  }
+  // column sharding: context g takes columns g, g + G, ...
+  for (size_t g = 0; g < G && g < m; g++) {
+    DevCtx& c = g_h2.ctx[g];
+    DeviceGuard dg(c.device);
+    const size_t mine = (m - g + G - 1) / G;
+    const size_t res_off = h2_align256(mine * col_bytes);
+    rc = arena_acquire(c.stage, res_off + mine * 96, c.stream);
+    if (rc != H2_OK) return rc;
+    for (size_t i = 0; i < mine; i++)
+      H2_TRY(hipMemcpyAsync((char*)c.stage.p + i * col_bytes, cols[g + i * G], col_bytes, hipMemcpyHostToDevice,
+                            c.stream));
+    void* d_res = (char*)c.stage.p + res_off;
+    rc = msm_device_run(c, (int)curve, *be, c.stage.p, 0, n, n, mine, d_res, affine_out, c.stream);
+    if (rc != H2_OK) return rc;
+    for (size_t i = 0; i < mine; i++)
+      H2_TRY(hipMemcpyAsync((char*)out + (g + i * G) * out_sz, (char*)d_res + i * out_sz, out_sz,
+                            hipMemcpyDeviceToHost, c.stream));
+  }
+  for (size_t g = 0; g < G && g < m; g++) {
+    DeviceGuard dg(g_h2.ctx[g].device);
+    H2_TRY(hipStreamSynchronize(g_h2.ctx[g].stream));
+  }
   return H2_OK;
 }
 
 int h2_msm(h2_curve_t curve, uint64_t handle, const uint64_t* scalars, size_t n, uint64_t out_jac[12]) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   if (n && !scalars) return H2_EINVAL;
   const uint64_t* cols[1] = {scalars ? scalars : (const uint64_t*)out_jac};
   return msm_host(curve, handle, cols, n, 1, out_jac, false);
@@ -434,193 +554,218 @@ int h2_msm(h2_curve_t curve, uint64_t handle, const uint64_t* scalars, size_t n,
 
 int h2_msm_batch(h2_curve_t curve, uint64_t handle, const uint64_t* const* scalars, size_t n, size_t m,
                  uint64_t* out_affine) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   return msm_host(curve, handle, scalars, n, m, out_affine, true);
 }
 
 int h2_srs_generate(h2_curve_t curve, const uint64_t s[4], size_t n, void* d_out_affine, void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   const CurveOps* ops = ops_of((int)curve);
   if (!ops || !s || !d_out_affine || n == 0 || n >= (1ull << 32)) return H2_EINVAL;
-  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
-  hipError_t e = ops->srs_powers(d_out_affine, s, (uint32_t)n, stream);
+  hipError_t e = ops->srs_powers(d_out_affine, s, (uint32_t)n, k.stream);
   if (e != hipSuccess) return dev_fail(e, "srs_powers_kernel");
   return H2_OK;
 }
 
 int h2_fixed_base_mul(h2_curve_t curve, const void* d_scalars, size_t n, void* d_out_affine, void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   const CurveOps* ops = ops_of((int)curve);
   if (!ops || !d_scalars || !d_out_affine || n == 0 || n >= (1ull << 32)) return H2_EINVAL;
-  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
-  hipError_t e = ops->fixed_base_mul(d_out_affine, d_scalars, (uint32_t)n, stream);
+  hipError_t e = ops->fixed_base_mul(d_out_affine, d_scalars, (uint32_t)n, k.stream);
   if (e != hipSuccess) return dev_fail(e, "fixed_base_mul_kernel");
   return H2_OK;
 }
 
 int h2_profile_enable(int on) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  g_ctx.profiling = on != 0;
-  g_ctx.prof_used = 0;
-  g_ctx.prof_alg_bytes = 0;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  g_h2.profiling = on != 0;
+  for (auto& c : g_h2.ctx) {
+    c.prof_used = 0;
+    c.prof_alg_bytes = 0;
+  }
   return H2_OK;
 }
 
 int h2_profile_read(h2_profile_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   if (!out) return H2_EINVAL;
-  double ms = 0;
-  for (size_t i = 0; i < g_ctx.prof_used; i++) {
-    float t = 0;
-    H2_TRY(hipEventSynchronize(g_ctx.prof_events[i].second));
-    H2_TRY(hipEventElapsedTime(&t, g_ctx.prof_events[i].first, g_ctx.prof_events[i].second));
-    ms += t;
+  double ms = 0, bytes = 0;
+  uint64_t launches = 0;
+  for (auto& c : g_h2.ctx) {
+    DeviceGuard dg(c.device);
+    for (size_t i = 0; i < c.prof_used; i++) {
+      float t = 0;
+      H2_TRY(hipEventSynchronize(c.prof_events[i].second));
+      H2_TRY(hipEventElapsedTime(&t, c.prof_events[i].first, c.prof_events[i].second));
+      ms += t;
+    }
+    launches += c.prof_used;
+    bytes += c.prof_alg_bytes;
+    c.prof_used = 0;
+    c.prof_alg_bytes = 0;
   }
-  out->launches = g_ctx.prof_used;
+  out->launches = launches;
   out->kernel_ms = ms;
-  out->algorithmic_bytes = g_ctx.prof_alg_bytes;
-  g_ctx.prof_used = 0;
-  g_ctx.prof_alg_bytes = 0;
+  out->algorithmic_bytes = bytes;
   return H2_OK;
 }
 
 int h2_ntt_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !omega || m == 0 || log_n > 30) return H2_EINVAL;
-  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
   if (log_n == 0) return H2_OK;
-  return ntt_enqueue((int)curve, d_a, m, omega, log_n, stream);
+  return ntt_enqueue(*k.c, (int)curve, d_a, m, omega, log_n, k.stream);
 }
 
 int h2_ntt_scaled_device(h2_curve_t curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n,
                          const uint64_t scale[4], void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !omega || !scale || m == 0 || log_n > 30) return H2_EINVAL;
-  hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_ctx.stream;
   if (log_n == 0) {
-    hipError_t e = ops_of((int)curve)->poly_scale(d_a, m, scale, stream);
+    hipError_t e = ops_of((int)curve)->poly_scale(d_a, m, scale, k.stream);
     if (e != hipSuccess) return dev_fail(e, "poly_scale_kernel");
     return H2_OK;
   }
-  return ntt_enqueue((int)curve, d_a, m, omega, log_n, stream, scale);
+  return ntt_enqueue(*k.c, (int)curve, d_a, m, omega, log_n, k.stream, scale);
 }
 
 int h2_poly_scale_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const uint64_t c[4], void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !c) return H2_EINVAL;
   if (n * m == 0) return H2_OK;
-  hipError_t e = ops_of((int)curve)->poly_scale(d_a, n * m, c, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  hipError_t e = ops_of((int)curve)->poly_scale(d_a, n * m, c, k.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_scale_kernel");
   return H2_OK;
 }
 
 int h2_poly_coset_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const uint64_t g[4], void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !g) return H2_EINVAL;
   if (n * m == 0) return H2_OK;
-  hipError_t e = ops_of((int)curve)->poly_powers(d_a, n, m, g, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  hipError_t e = ops_of((int)curve)->poly_powers(d_a, n, m, g, k.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_powers_kernel");
   return H2_OK;
 }
 
 int h2_poly_mul_periodic_device(h2_curve_t curve, void* d_a, size_t n, size_t m, const void* d_t, size_t period,
                                 void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !d_t || period == 0 || (period & (period - 1))) return H2_EINVAL;
   if (n * m == 0) return H2_OK;
-  hipError_t e = ops_of((int)curve)->poly_mul_periodic(d_a, n * m, d_t, period,
-                                                     stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  hipError_t e = ops_of((int)curve)->poly_mul_periodic(d_a, n * m, d_t, period, k.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_mul_periodic_kernel");
   return H2_OK;
 }
 
 int h2_poly_inverse_device(h2_curve_t curve, void* d_a, size_t n, void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a) return H2_EINVAL;
   if (n == 0) return H2_OK;
-  hipError_t e = ops_of((int)curve)->poly_inverse(d_a, n, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  hipError_t e = ops_of((int)curve)->poly_inverse(d_a, n, k.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_inverse_kernel");
   return H2_OK;
 }
 
 int h2_poly_divide_linear_device(h2_curve_t curve, const void* d_a, size_t n, const uint64_t z[4], void* d_q,
                                  void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !d_q || !z || d_a == d_q) return H2_EINVAL;
   if (n == 0) return H2_OK;
-  if (!g_ctx.div_ws) H2_TRY(hipMalloc(&g_ctx.div_ws, (size_t)2 * DIV_MAX_CHUNKS * 32));
-  hipError_t e = ops_of((int)curve)->poly_divide_linear(d_a, n, z, d_q, g_ctx.div_ws,
-                                                        stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  int rc = arena_acquire(k.c->div_ws, (size_t)2 * DIV_MAX_CHUNKS * 32, k.stream);
+  if (rc != H2_OK) return rc;
+  hipError_t e = ops_of((int)curve)->poly_divide_linear(d_a, n, z, d_q, k.c->div_ws.p, k.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_divide kernels");
-  return H2_OK;
+  return arena_release(k.c->div_ws, k.stream);
 }
 
 int h2_poly_prefix_product_device(h2_curve_t curve, const void* d_a, size_t n, void* d_out, void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !d_out) return H2_EINVAL;
   if (n == 0) return H2_OK;
-  if (!g_ctx.div_ws) H2_TRY(hipMalloc(&g_ctx.div_ws, (size_t)2 * DIV_MAX_CHUNKS * 32));
-  hipError_t e = ops_of((int)curve)->poly_prefix_product(d_a, n, d_out, g_ctx.div_ws,
-                                                         stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  int rc = arena_acquire(k.c->div_ws, (size_t)2 * DIV_MAX_CHUNKS * 32, k.stream);
+  if (rc != H2_OK) return rc;
+  hipError_t e = ops_of((int)curve)->poly_prefix_product(d_a, n, d_out, k.c->div_ws.p, k.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_prefix kernels");
-  return H2_OK;
+  return arena_release(k.c->div_ws, k.stream);
 }
 
 int h2_chacha20_scalars_device(h2_curve_t curve, const uint8_t seed[32], uint64_t first_block, size_t n, void* d_out,
                                void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !seed || !d_out) return H2_EINVAL;
   if (n == 0) return H2_OK;
   uint32_t key[8];
   for (int i = 0; i < 8; i++)
     key[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) |
              ((uint32_t)seed[4 * i + 3] << 24);
-  hipError_t e = ops_of((int)curve)->chacha20_scalars(d_out, n, first_block, key,
-                                                      stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  hipError_t e = ops_of((int)curve)->chacha20_scalars(d_out, n, first_block, key, k.stream);
   if (e != hipSuccess) return dev_fail(e, "chacha20_scalars_kernel");
   return H2_OK;
 }
 
 int h2_poly_pointwise_device(h2_curve_t curve, int op, void* d_a, const void* d_b, size_t n, void* stream_) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
   if (!curve_ok((int)curve) || !d_a || !d_b || op < 0 || op > 2) return H2_EINVAL;
   if (n == 0) return H2_OK;
-  hipError_t e = ops_of((int)curve)->poly_pointwise(d_a, d_b, n, op, stream_ ? (hipStream_t)stream_ : g_ctx.stream);
+  hipError_t e = ops_of((int)curve)->poly_pointwise(d_a, d_b, n, op, k.stream);
   if (e != hipSuccess) return dev_fail(e, "poly_pointwise_kernel");
   return H2_OK;
 }
 
+// host columns; with several contexts column j is transformed by context j mod G (a single NTT is not split:
+// "replicas only")
 int h2_ntt_batch(h2_curve_t curve, uint64_t* const* cols, size_t m, const uint64_t omega[4], uint32_t log_n) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
   if (!curve_ok((int)curve) || !cols || !omega || m == 0 || log_n > 30) return H2_EINVAL;
   for (size_t j = 0; j < m; j++)
     if (!cols[j]) return H2_EINVAL;
   if (log_n == 0) return H2_OK;
   const size_t col_bytes = (size_t)32 << log_n;
-  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, m * col_bytes);
-  if (rc != H2_OK) return rc;
-  for (size_t j = 0; j < m; j++)
-    H2_TRY(hipMemcpyAsync((char*)g_ctx.stage + j * col_bytes, cols[j], col_bytes, hipMemcpyHostToDevice,
-                          g_ctx.stream));
-  rc = ntt_enqueue((int)curve, g_ctx.stage, m, omega, log_n, g_ctx.stream);
-  if (rc != H2_OK) return rc;
-  for (size_t j = 0; j < m; j++)
-    H2_TRY(hipMemcpyAsync(cols[j], (char*)g_ctx.stage + j * col_bytes, col_bytes, hipMemcpyDeviceToHost,
-                          g_ctx.stream));
-  H2_TRY(hipStreamSynchronize(g_ctx.stream));
+  const size_t G = g_h2.ctx.size();
+  for (size_t g = 0; g < G && g < m; g++) {
+    DevCtx& c = g_h2.ctx[g];
+    DeviceGuard dg(c.device);
+    const size_t mine = (m - g + G - 1) / G;
+    int rc = arena_acquire(c.stage, mine * col_bytes, c.stream);
+    if (rc != H2_OK) return rc;
+    for (size_t i = 0; i < mine; i++)
+      H2_TRY(hipMemcpyAsync((char*)c.stage.p + i * col_bytes, cols[g + i * G], col_bytes, hipMemcpyHostToDevice,
+                            c.stream));
+    rc = ntt_enqueue(c, (int)curve, c.stage.p, mine, omega, log_n, c.stream);
+    if (rc != H2_OK) return rc;
+    for (size_t i = 0; i < mine; i++)
+      H2_TRY(hipMemcpyAsync(cols[g + i * G], (char*)c.stage.p + i * col_bytes, col_bytes, hipMemcpyDeviceToHost,
+                            c.stream));
+  }
+  for (size_t g = 0; g < G && g < m; g++) {
+    DeviceGuard dg(g_h2.ctx[g].device);
+    H2_TRY(hipStreamSynchronize(g_h2.ctx[g].stream));
+  }
   return H2_OK;
 }
 
@@ -658,13 +803,15 @@ extern "C" int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_
 // n element pairs through the DEVICE instantiation (one kernel launch); host pointers in and out
 extern "C" int h2_selftest_curve_op_device(int curve, int op, const uint64_t* p, const uint64_t* q, uint64_t* out,
                                            size_t n) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
   const CurveOps* ops = ops_of(curve);
   if (!ops || !p || !q || !out || n == 0 || n > (1u << 20)) return H2_EINVAL;
-  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, 3 * n * 64);
+  DevCtx& g_ctx = g_h2.ctx[0];
+  DeviceGuard dg(g_ctx.device);
+  int rc = arena_acquire(g_ctx.stage, 3 * n * 64, g_ctx.stream);
   if (rc != H2_OK) return rc;
-  char* d = (char*)g_ctx.stage;
+  char* d = (char*)g_ctx.stage.p;
   H2_TRY(hipMemcpyAsync(d, p, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
   H2_TRY(hipMemcpyAsync(d + n * 64, q, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
   hipError_t e = ops->selftest_curve_device(op, d, d + n * 64, d + 2 * n * 64, (uint32_t)n, g_ctx.stream);
@@ -676,19 +823,44 @@ extern "C" int h2_selftest_curve_op_device(int curve, int op, const uint64_t* p,
 
 extern "C" int h2_selftest_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                                            size_t n) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return H2_ENOTINIT;
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
   if (!a || !b || !out || n == 0 || n > (1u << 24) || field < 0 || field > 3) return H2_EINVAL;
   const CurveOps* ops = field < 2 ? curve_ops_bn254() : curve_ops_pallas();
   const int which = field & 1;
-  int rc = ensure_arena(&g_ctx.stage, &g_ctx.stage_bytes, 3 * n * 32);
+  DevCtx& g_ctx = g_h2.ctx[0];
+  DeviceGuard dg(g_ctx.device);
+  int rc = arena_acquire(g_ctx.stage, 3 * n * 32, g_ctx.stream);
   if (rc != H2_OK) return rc;
-  char* d = (char*)g_ctx.stage;
+  char* d = (char*)g_ctx.stage.p;
   H2_TRY(hipMemcpyAsync(d, a, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
   H2_TRY(hipMemcpyAsync(d + n * 32, b, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
   hipError_t e = ops->selftest_field_device(which, op, d, d + n * 32, d + 2 * n * 32, (uint32_t)n, g_ctx.stream);
   if (e != hipSuccess) return dev_fail(e, "selftest_field_kernel");
   H2_TRY(hipMemcpyAsync(out, d + 2 * n * 32, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
   H2_TRY(hipStreamSynchronize(g_ctx.stream));
+  return H2_OK;
+}
+
+// test hook: lower the sort's entry limit so that the grouped-columns path is reached at small sizes (0 = default)
+extern "C" int h2_selftest_set_msm_max_entries(uint64_t limit) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  h2::g_msm_max_entries = (limit > 0 && limit < (1ull << 31) - 1) ? limit : (1ull << 31) - 1;
+  return H2_OK;
+}
+
+// measured integer ceiling: dependent 9 x 29-bit Montgomery products of `curve`'s base field at `waves_per_simd`
+// resident waves per SIMD on every CU of the current device
+extern "C" int h2_selftest_modmul_rate(int curve, int waves_per_simd, int iters, double* modmul_per_s) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
+  const CurveOps* ops = ops_of(curve);
+  if (!ops || !modmul_per_s || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 20)) return H2_EINVAL;
+  DevCtx* c = ctx_current();
+  if (!c) return H2_EINVAL;
+  hipDeviceProp_t prop;
+  H2_TRY(hipGetDeviceProperties(&prop, c->device));
+  hipError_t e = ops->modmul_rate(prop.multiProcessorCount * waves_per_simd, iters, c->stream, modmul_per_s);
+  if (e != hipSuccess) return dev_fail(e, "modmul_rate_kernel");
   return H2_OK;
 }

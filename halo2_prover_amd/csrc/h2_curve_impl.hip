@@ -23,15 +23,20 @@ using CV = VESTA_CURVE;
 using FS = typename CV::Scalar;
 using FB = typename CV::Base;
 
+hipError_t kernel_setup() {
+  hipError_t e = msm_kernel_setup<CV>();
+  if (e != hipSuccess) return e;
+  return ntt_kernel_setup<FS>();
+}
 hipError_t table_build(const void* d_bases, void* d_table, uint32_t n, const MsmGeom& g, hipStream_t s) {
   hipLaunchKernelGGL(msm_table_kernel<CV>, dim3((n + 255) / 256), dim3(256), 0, s, (const U128*)d_bases,
                      (U128*)d_table, n, g);
   return hipGetLastError();
 }
-hipError_t msm_launch_(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t m,
+hipError_t msm_launch_(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
                        const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s, hipEvent_t ev_start,
                        hipEvent_t ev_stop) {
-  return msm_launch<CV>((const U128*)d_table, n_bases, (const U128*)d_scalars, n, m, g, ws_base, ws, s, ev_start,
+  return msm_launch<CV>((const U128*)d_table, n_bases, (const U128*)d_scalars, n, col_stride, m, g, ws_base, ws, s, ev_start,
                         ev_stop);
 }
 hipError_t srs_powers(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s) {
@@ -53,6 +58,11 @@ hipError_t to_jacobian(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t 
 hipError_t to_affine(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
   hipLaunchKernelGGL(msm_to_affine_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const uint32_t*)d_xyzz,
                      (U128*)d_out, m);
+  return hipGetLastError();
+}
+hipError_t points_sum(const void* d_in_jac, void* d_out_jac, uint32_t groups, uint32_t count, hipStream_t s) {
+  hipLaunchKernelGGL(points_sum_kernel<CV>, dim3((count + 63) / 64), dim3(64), 0, s, (const U128*)d_in_jac,
+                     (U128*)d_out_jac, groups, count);
   return hipGetLastError();
 }
 hipError_t ntt_twiddles(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s) {
@@ -108,6 +118,46 @@ hipError_t poly_pointwise(void* d_a, const void* d_b, size_t total, int op, hipS
   hipLaunchKernelGGL(poly_pointwise_kernel<FS>, dim3(poly_grid(total)), dim3(256), 0, s, (U128*)d_a,
                      (const U128*)d_b, total, op);
   return hipGetLastError();
+}
+
+// the ceiling the MSM kernels are priced against (bench.py `modmul_ceiling`): dependent products of the working
+// form (h2_field29.hpp) over the base field, `blocks` x 256 threads, best of three launches
+__global__ void __launch_bounds__(256) modmul_rate_kernel(uint32_t* out, int iters) {
+  Fe29<FB> a, b;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    a.v[i] = (int32_t)((0x1234567u * (i + 1) + threadIdx.x * 2654435761u) & L29_MASK);
+    b.v[i] = (int32_t)((0x7654321u * (i + 3) + blockIdx.x * 40503u) & L29_MASK);
+  }
+  a.v[8] &= 0xFFFFF;
+  b.v[8] &= 0xFFFFF;      // values below 2^252
+  for (int k = 0; k < iters; k++) a = fe29_mul(a, b);
+  uint32_t* o = out + 9 * (size_t)(blockIdx.x * blockDim.x + threadIdx.x);
+#pragma unroll
+  for (int i = 0; i < 9; i++) o[i] = (uint32_t)a.v[i];
+}
+hipError_t modmul_rate(int blocks, int iters, hipStream_t s, double* modmul_per_s) {
+  void* buf = nullptr;
+  hipError_t e = hipMalloc(&buf, (size_t)blocks * 256 * 9 * 4);
+  if (e != hipSuccess) return e;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int r = 0; r < 4 && e == hipSuccess; r++) {          // the first launch is a warm-up
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(modmul_rate_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)buf, iters);
+    (void)hipEventRecord(e1, s);
+    e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0 && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  if (e == hipSuccess) *modmul_per_s = (double)blocks * 256.0 * iters / (best * 1e-3);
+  return e;
 }
 
 template <class FP>
@@ -269,10 +319,10 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
   return carry ? -2 : 0;  // a carry out of the top window would lose value
 }
 
-const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, table_build, msm_launch_,    srs_powers, fixed_base_mul,
-                      to_jacobian, to_affine,   ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
+const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, kernel_setup, table_build, msm_launch_,    srs_powers, fixed_base_mul,
+                      to_jacobian, to_affine,   points_sum, ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
                       poly_pointwise, poly_inverse, poly_divide_linear, poly_prefix_product, chacha20_scalars, selftest_field, selftest_curve,
-                      selftest_field_device, selftest_curve_device, selftest_digits};
+                      selftest_field_device, selftest_curve_device, selftest_digits, modmul_rate};
 
 }  // namespace
 

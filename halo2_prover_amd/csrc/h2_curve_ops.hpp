@@ -16,15 +16,19 @@ struct CurveOps {
   int curve_id;
   int scalar_field_id;
   uint32_t scalar_bits;
+  // raise the dynamic-LDS limits of this curve's kernels on the current device (once per device, from h2_init)
+  hipError_t (*kernel_setup)();
   // MSM
   hipError_t (*table_build)(const void* d_bases, void* d_table, uint32_t n, const MsmGeom& g, hipStream_t s);
-  hipError_t (*msm_launch)(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t m,
+  hipError_t (*msm_launch)(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
                            const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s,
                            hipEvent_t ev_start, hipEvent_t ev_stop);
   hipError_t (*srs_powers)(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s);
   hipError_t (*fixed_base_mul)(void* d_out_affine, const void* d_scalars, uint32_t n, hipStream_t s);
   hipError_t (*to_jacobian)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
   hipError_t (*to_affine)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
+  // d_out[j] = sum_g d_in[g * count + j], Jacobian points in the API form
+  hipError_t (*points_sum)(const void* d_in_jac, void* d_out_jac, uint32_t groups, uint32_t count, hipStream_t s);
   // NTT over the scalar field
   hipError_t (*ntt_twiddles)(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s);
   hipError_t (*ntt_launch)(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m,
@@ -52,6 +56,8 @@ struct CurveOps {
   // double, 5: [k]p by the weight kernel's double-and-add with a different k per quad)
   hipError_t (*selftest_curve_device)(int op, const void* d_p, const void* d_q, void* d_out, uint32_t n, hipStream_t s);
   int (*selftest_digits)(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t* out, uint32_t cap);
+  // dependent working-form products of the base field on `blocks` x 256 threads: measured modmul/s (best of 3)
+  hipError_t (*modmul_rate)(int blocks, int iters, hipStream_t s, double* modmul_per_s);
 };
 
 const CurveOps* curve_ops_bn254();

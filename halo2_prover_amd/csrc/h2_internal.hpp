@@ -1,0 +1,106 @@
+// h2_internal.hpp -- state shared by the translation units behind the C ABI (h2_capi.hip and the C++ prover).
+//
+// One DevCtx per GPU the process drives (h2_init: one; h2_init_devices: several).  Every scratch arena remembers the
+// stream that used it last and an event recorded behind that use, so a call on ANOTHER stream first waits for it:
+// callers may hand any stream to the *_device entry points (include/h2hip.h, threading paragraph).  The MSM and the
+// NTT have separate arenas, so an MSM on one stream and an NTT on another do overlap.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/h2hip.h"
+#include "h2_curve_ops.hpp"
+#include "h2_msm.hpp"
+
+namespace h2 {
+
+struct Arena {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipEvent_t ev = nullptr;        // recorded after the last enqueue that used the arena
+  hipStream_t last = nullptr;
+  bool used = false;
+};
+
+struct TwiddleEntry {
+  int field;
+  uint32_t log_n;
+  uint64_t omega[4];
+  void* tw;
+  uint64_t stamp;
+};
+
+struct DevCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;   // the library's own (blocking) stream on this device
+  Arena msm_ws, ntt_ws, stage, div_ws;
+  std::vector<TwiddleEntry> twiddles;
+  uint64_t stamp = 0;
+  // kernel timing for the roofline (h2_profile_*): event pairs around the bucket-accumulate kernel
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_alg_bytes = 0;
+};
+
+struct BasesEntry {
+  int curve;
+  size_t n;
+  MsmGeom geom;
+  std::vector<void*> table;       // per context: W * n affine points in the working form
+  size_t table_bytes;
+};
+
+struct Global {
+  bool ready = false;
+  std::vector<DevCtx> ctx;
+  std::map<uint64_t, BasesEntry> bases;
+  uint64_t next_handle = 1;
+  bool profiling = false;
+  std::string last_error;
+};
+
+extern Global g_h2;
+extern std::recursive_mutex g_h2_mu;
+
+// the process's current HIP device is switched for the lifetime of the guard
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+int dev_fail(hipError_t e, const char* where);
+const CurveOps* ops_of(int curve);
+bool curve_ok(int c);
+// context of the calling thread's current HIP device (the only context when there is just one); null if none
+DevCtx* ctx_current();
+size_t ctx_index(const DevCtx* c);
+
+// arenas: acquire = grow if needed + order `s` behind the previous user; release = record the event behind this use
+int arena_acquire(Arena& a, size_t want, hipStream_t s);
+int arena_release(Arena& a, hipStream_t s);
+
+// enqueue m MSMs (columns of n scalars, col_stride elements apart, bases first_base ... first_base + n - 1 of the
+// registered vector) -> m Jacobian (96 B) or affine (64 B) points at d_out; all on `stream`
+int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_scalars, size_t first_base, size_t n,
+                   size_t col_stride, size_t m, void* d_out, bool affine_out, hipStream_t stream);
+int ntt_enqueue(DevCtx& c, int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream,
+                const uint64_t* scale = nullptr);
+int msm_common_checks(int curve, uint64_t handle, size_t first, size_t n, size_t m, const BasesEntry** be);
+
+#define H2_TRY(call)                                        \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return ::h2::dev_fail(_e, #call); \
+  } while (0)
+
+}  // namespace h2

@@ -536,6 +536,29 @@ __global__ void msm_to_affine_kernel(const uint32_t* __restrict__ in, U128* __re
   fe_store<B>(out_aff + 4 * (size_t)col + 2, a.y);
 }
 
+// out[j] = sum_{g < groups} in[g * count + j], Jacobian in and out (API form): the partial sums of an MSM split by
+// point range over several GPUs are added here after the all-gather
+template <class CV>
+__global__ void points_sum_kernel(const U128* __restrict__ in_jac, U128* __restrict__ out_jac, uint32_t groups,
+                                  uint32_t count) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  using B = typename CV::Base;
+  Xyzz<CV> acc = Xyzz<CV>::identity();
+  for (uint32_t g = 0; g < groups; g++) {
+    const U128* p = in_jac + 6 * ((size_t)g * count + j);
+    const Fe<B> x = fe_load<B>(p), y = fe_load<B>(p + 2), z = fe_load<B>(p + 4);
+    if (z.is_zero()) continue;
+    const Fe<B> zz = fe_sqr(z);
+    acc = xyzz_add(acc, Xyzz<CV>{x, y, zz, fe_mul(zz, z)});
+  }
+  Fe<B> x, y, z;
+  xyzz_to_jacobian(acc, x, y, z);
+  fe_store<B>(out_jac + 6 * (size_t)j, x);
+  fe_store<B>(out_jac + 6 * (size_t)j + 2, y);
+  fe_store<B>(out_jac + 6 * (size_t)j + 4, z);
+}
+
 // ---- SRS generation: g[i] = [s^i] G  (ParamsKZG::new's coefficient-basis vector) -----------------
 // Device counterpart of the setup loop reached from /root/reference/circuits/src/utils.rs:59-61
 // (SURVEY.md section 3.2).  One thread per point: s^i by square-and-multiply, then a 255-step
@@ -671,12 +694,23 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   return ws;
 }
 
-// Enqueue m MSMs of n terms against `table` (built for n_bases points with geometry g).
+// once per device (h2_init): the sort kernels and the one-block scan use more than the default 64 KiB of dynamic LDS
+template <class CV>
+inline hipError_t msm_kernel_setup() {
+  hipError_t e;
+  const int lds = (int)((1u << (MSM_MAX_C - 1)) * 4);
+  if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)scan_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCAN_LDS_MAX * 4));
+}
+
+// Enqueue m MSMs of n terms against `table` (built for n_bases points with geometry g); column j's scalars start
+// col_stride elements after column j-1's.
 // Result: m XYZZ points at ws_base + off_tree2.  ev_start / ev_stop (optional) bracket the
 // accumulate (chunk) kernel for the roofline measurement.
 template <class CV>
-inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_scalars, size_t n, size_t m,
-                             const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
+inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_scalars, size_t n, size_t col_stride,
+                             size_t m, const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
@@ -700,21 +734,13 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   // head / tail that a later kernel reads has been written by the accumulate kernel (the fix-up decides from
   // `offsets` which slots exist).
   if ((e = hipMemsetAsync(misc, 0, 256 + ws.K * 4, stream)) != hipSuccess) return e;
-  const size_t lds = (size_t)g.B * 4;
-  if (lds > 48 * 1024) {
-    if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds)) != hipSuccess) return e;
-  }
+  const size_t lds = (size_t)g.B * 4;     // dynamic LDS limits were raised once per device by msm_kernel_setup
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
   hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, counts,
-                     tile_base, (uint32_t)n, n, ws.tile, g);
+                     tile_base, (uint32_t)n, col_stride, ws.tile, g);
   if (ws.K <= SCAN_LDS_MAX) {
     uint32_t per = (uint32_t)((ws.K + 1023) / 1024);
     per |= 1u;                                 // odd stride: the per-thread LDS walks do not collide on banks
-    if ((e = hipFuncSetAttribute((const void*)scan_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(SCAN_LDS_MAX * 4))) != hipSuccess) return e;
     hipLaunchKernelGGL(scan_lds_kernel, dim3(1), dim3(1024), ws.K * 4, stream, counts, offsets, (uint32_t)ws.K, per);
   } else {
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
@@ -723,7 +749,7 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
                      ws.K);
   }
   hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
-                     tile_base, sref, (uint32_t)n, n, n_bases, ws.tile, g);
+                     tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
   if (ev_start) (void)hipEventRecord(ev_start, stream);

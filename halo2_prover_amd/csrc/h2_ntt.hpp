@@ -286,17 +286,19 @@ inline hipError_t ntt_launch(U128* data, U128* scratch, const U128* tw, uint32_t
     else if (p == pl.npass - 1) { src = scratch; dst = data; }
     else { src = scratch; dst = scratch; }
     dim3 grid(pl.tiles[p], (unsigned)m);
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<FP>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
     NttPass P = pl.pass[p];
     P.has_scale = (scale && P.is_final) ? 1u : 0u;
     hipLaunchKernelGGL(ntt_pass_kernel<FP>, grid, dim3(pl.threads[p]), pl.lds_bytes[p], stream, src, dst, tw, P, n,
                        sc);
-    e = hipGetLastError();
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
+}
+// once per device (h2_init): the tile kernel may use the whole 160 KiB of LDS
+template <class FP>
+inline hipError_t ntt_kernel_setup() {
+  return hipFuncSetAttribute((const void*)ntt_pass_kernel<FP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <class FP>

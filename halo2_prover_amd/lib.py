@@ -13,7 +13,8 @@ H2_BN254, H2_PALLAS, H2_VESTA = 0, 1, 2
 CURVES = {"bn254": H2_BN254, "pallas": H2_PALLAS, "vesta": H2_VESTA}
 
 H2_OK = 0
-STATUS_NAMES = {0: "H2_OK", -1: "H2_EINVAL", -2: "H2_ENOMEM", -3: "H2_EDEVICE", -4: "H2_EHANDLE", -5: "H2_ENOTINIT"}
+STATUS_NAMES = {0: "H2_OK", -1: "H2_EINVAL", -2: "H2_ENOMEM", -3: "H2_EDEVICE", -4: "H2_EHANDLE", -5: "H2_ENOTINIT",
+                -6: "H2_EPROOF"}
 
 # every symbol include/h2hip.h declares: name -> (restype, argtypes)
 _P, _Z, _I, _U32, _U64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
@@ -29,6 +30,8 @@ class MsmPlan(ctypes.Structure):
 
 SYMBOLS = {
     "h2_init": (_I, [_I]),
+    "h2_init_devices": (_I, [_I, _P]),
+    "h2_device_count": (_I, []),
     "h2_shutdown": (_I, []),
     "h2_strerror": (ctypes.c_char_p, [_I]),
     "h2_last_device_error": (ctypes.c_char_p, []),
@@ -40,6 +43,8 @@ SYMBOLS = {
     "h2_msm": (_I, [_I, _U64, _P, _Z, _P]),
     "h2_msm_batch": (_I, [_I, _U64, _P, _Z, _Z, _P]),
     "h2_msm_device": (_I, [_I, _U64, _P, _Z, _Z, _P, _P]),
+    "h2_msm_device_range": (_I, [_I, _U64, _P, _Z, _Z, _Z, _Z, _P, _P]),
+    "h2_points_sum_device": (_I, [_I, _P, _Z, _Z, _P, _P]),
     "h2_ntt": (_I, [_I, _P, _P, _U32]),
     "h2_ntt_batch": (_I, [_I, _P, _Z, _P, _U32]),
     "h2_ntt_device": (_I, [_I, _P, _Z, _P, _U32, _P]),
@@ -65,6 +70,8 @@ SELFTEST_SYMBOLS = {
     "h2_selftest_digits": (_I, [_I, _P, _Z, _P, _U32]),
     "h2_selftest_field_op_device": (_I, [_I, _I, _P, _P, _P, _Z]),
     "h2_selftest_curve_op_device": (_I, [_I, _I, _P, _P, _P, _Z]),
+    "h2_selftest_set_msm_max_entries": (_I, [_U64]),
+    "h2_selftest_modmul_rate": (_I, [_I, _I, _I, ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

@@ -728,19 +728,18 @@ class _Dev:
         import torch.distributed as dist
         m, n = cols.shape[0], cols.shape[1]
         bases = self.params._gl if lagrange else self.params._g
-        sharded = (dist.is_available() and dist.is_initialized() and m > 1 and
+        sharded = (dist.is_available() and dist.is_initialized() and
                    (dist.get_world_size() > 1 or _sharded.FORCE_GATHER))
-        if sharded:
-            # one process per GPU: column j of the phase is committed by rank j mod world, then ONE all-gather of the
-            # 96-byte results gives every rank the whole vector for its transcript
-            mine = _sharded.shard_columns(m, dist.get_rank(), dist.get_world_size())
-            cols = cols[mine]
         cols = cols.contiguous()
-        out = self.torch.zeros((cols.shape[0], 12), dtype=self.torch.int64, device="cuda")
-        if cols.shape[0]:
-            bases.msm_device(cols.data_ptr(), n, cols.shape[0], out.data_ptr(), self.dom._stream().value or 0)
+        stream = self.dom._stream().value or 0
         if sharded:
-            out = _sharded.gather_columns(out, m)
+            # one process per GPU: whole columns per rank when m divides evenly, else every rank takes a point range of
+            # every column; ONE all-gather of 96-byte points per phase either way
+            mode = None if dist.get_world_size() > 1 else "range"
+            out = _sharded.msm_phase_device(bases, cols.data_ptr(), n, m, stream, mode=mode)
+        else:
+            out = self.torch.zeros((m, 12), dtype=self.torch.int64, device="cuda")
+            bases.msm_device(cols.data_ptr(), n, m, out.data_ptr(), stream)
         self.torch.cuda.synchronize()
         raw = out.cpu().numpy().tobytes()
         pts = []
@@ -852,9 +851,12 @@ def generate_params(k, rng=None):
     s = rng.fr_random()
     n = 1 << k
     L = _lib.load()
+    # every library call below goes to torch's CURRENT stream: the inputs are produced by torch kernels on that stream
+    # (the library's own blocking stream would only be ordered against the null stream)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     g_dev = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     s_m = _limbs_of([s])
-    _lib.check(L.h2_srs_generate(0, s_m.ctypes.data, n, ctypes.c_void_p(g_dev.data_ptr()), None), "h2_srs_generate")
+    _lib.check(L.h2_srs_generate(0, s_m.ctypes.data, n, ctypes.c_void_p(g_dev.data_ptr()), st), "h2_srs_generate")
     # L_i(s) = w^i (s^n - 1) / (n (s - w^i)), all 2^k of them on the device: the column w^i (coset kernel on a column
     # of ones), s - w^i, a per-element inversion, two pointwise products
     omega = pow(ROOT_OF_UNITY, 1 << (TWO_ADICITY - k), P)
@@ -869,16 +871,16 @@ def generate_params(k, rng=None):
             return ctypes.c_void_p(t.data_ptr())
 
         ws = col_of(1)
-        _lib.check(L.h2_poly_coset_device(0, ptr(ws), n, 1, _limbs_of([omega]).ctypes.data, None), "h2_poly_coset_device")
+        _lib.check(L.h2_poly_coset_device(0, ptr(ws), n, 1, _limbs_of([omega]).ctypes.data, st), "h2_poly_coset_device")
         den = col_of(s)
-        _lib.check(L.h2_poly_pointwise_device(0, 1, ptr(den), ptr(ws), n, None), "h2_poly_pointwise_device")   # s - w^i
-        _lib.check(L.h2_poly_inverse_device(0, ptr(den), n, None), "h2_poly_inverse_device")
-        _lib.check(L.h2_poly_pointwise_device(0, 2, ptr(den), ptr(ws), n, None), "h2_poly_pointwise_device")   # w^i / (s - w^i)
+        _lib.check(L.h2_poly_pointwise_device(0, 1, ptr(den), ptr(ws), n, st), "h2_poly_pointwise_device")   # s - w^i
+        _lib.check(L.h2_poly_inverse_device(0, ptr(den), n, st), "h2_poly_inverse_device")
+        _lib.check(L.h2_poly_pointwise_device(0, 2, ptr(den), ptr(ws), n, st), "h2_poly_pointwise_device")   # w^i / (s - w^i)
         t = (pow(s, n, P) - 1) * pow(n, -1, P) % P
-        _lib.check(L.h2_poly_scale_device(0, ptr(den), n, 1, _limbs_of([t]).ctypes.data, None), "h2_poly_scale_device")
+        _lib.check(L.h2_poly_scale_device(0, ptr(den), n, 1, _limbs_of([t]).ctypes.data, st), "h2_poly_scale_device")
         sc_dev = den
     gl_dev = torch.empty((n, 8), dtype=torch.int64, device="cuda")
-    _lib.check(L.h2_fixed_base_mul(0, ctypes.c_void_p(sc_dev.data_ptr()), n, ctypes.c_void_p(gl_dev.data_ptr()), None),
+    _lib.check(L.h2_fixed_base_mul(0, ctypes.c_void_p(sc_dev.data_ptr()), n, ctypes.c_void_p(gl_dev.data_ptr()), st),
                "h2_fixed_base_mul")
     torch.cuda.synchronize()
     g = g_dev.cpu().numpy().view(np.uint64)

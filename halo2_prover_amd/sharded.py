@@ -65,6 +65,73 @@ def commit_columns(bases, columns, group=None, msm_batch=None):
     return out.cpu().numpy().view(np.uint64).reshape(m, 8)
 
 
+def phase_mode(m, world):
+    """how a commit phase of m columns is spread over `world` ranks: whole columns (column j -> rank j mod world) when
+    that balances exactly, else every rank takes a contiguous point range of EVERY column (SURVEY.md section 8(e):
+    real proofs have m = 1..5 per phase, fewer than the GPUs of a node)"""
+    if world <= 1:
+        return "single"
+    return "columns" if m % world == 0 else "range"
+
+
+def all_gather_rows(local, group=None):
+    """(rows, w) int64 tensor -> (world, rows, w) on every rank.  RCCL gathers device tensors in place; any other
+    backend (gloo in the tests and on boxes with fewer GPUs than ranks) goes through host memory."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rows, w = local.shape
+    if dist.get_backend(group) == "nccl":
+        recv = torch.empty((world * rows, w), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(recv, local.contiguous(), group=group)
+        return recv.view(world, rows, w)
+    host = local.cpu().contiguous()
+    recv = torch.empty((world * rows, w), dtype=host.dtype)
+    dist.all_gather_into_tensor(recv, host, group=group)
+    return recv.view(world, rows, w).to(local.device)
+
+
+def msm_phase_device(bases, d_cols, n, m, stream=0, group=None, mode=None, device=None):
+    """The m commitments of one proof phase on the GPUs of `group`: d_cols is a device pointer to m columns of n
+    scalars (stride n), identical on every rank; returns an (m, 12) int64 CUDA tensor of Jacobian points, the same
+    group elements on every rank, in column order.
+
+    "columns": rank r runs columns r, r + world, ... whole, one all-gather of the 96-byte results.
+    "range":   rank r runs bases / rows [n r / world, n (r+1) / world) of every column in one batched launch
+               (h2_msm_device_range), the world x m partial sums are all-gathered and added on the device
+               (h2_points_sum_device) -- BASELINE config 4's split of a single MSM, applied to every column.
+    Either way ONE collective per phase, m * 96 bytes per rank; scalars and bases never cross GPUs.
+    `device` defaults to the current CUDA device (the CPU tests of the sharding logic pass "cpu" and a stand-in
+    `bases` object)."""
+    import torch
+    import torch.distributed as dist
+    have_group = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if have_group else 1
+    rank = dist.get_rank(group) if have_group else 0
+    mode = mode or phase_mode(m, world)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if mode == "single" or not have_group:
+        out = torch.empty((m, 12), dtype=torch.int64, device=dev)
+        bases.msm_device_range(d_cols, 0, n, n, m, out.data_ptr(), stream)
+        return out
+    if mode == "columns":
+        mine = len(range(rank, m, world))
+        slots = (m + world - 1) // world
+        local = torch.zeros((slots, 12), dtype=torch.int64, device=dev)
+        if mine:
+            bases.msm_device_range(d_cols + rank * n * 32, 0, n, world * n, mine, local.data_ptr(), stream)
+        allr = all_gather_rows(local, group)                    # (world, slots, 12): column r + i * world at [r][i]
+        return allr.transpose(0, 1).reshape(slots * world, 12)[:m].contiguous()
+    lo, hi = split_msm_by_range(n, rank, world)
+    local = torch.zeros((m, 12), dtype=torch.int64, device=dev)
+    if hi > lo:
+        bases.msm_device_range(d_cols + lo * 32, lo, hi - lo, n, m, local.data_ptr(), stream)
+    allr = all_gather_rows(local, group)                        # (world, m, 12)
+    out = torch.empty((m, 12), dtype=torch.int64, device=dev)
+    bases.points_sum_device(allr.data_ptr(), world, m, out.data_ptr(), stream)
+    return out
+
+
 def split_msm_by_range(n, rank, world):
     """contiguous point range of a single large MSM handled by `rank`:
     each rank returns one partial sum, the partials are all-gathered and added (the group is abelian)."""

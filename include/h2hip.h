@@ -21,10 +21,24 @@
  *   Jacobian point = x || y || z, identity has z = 0                               96 bytes
  * All functions return 0 on success or a negative h2_status_t; they never abort or throw
  * across the ABI (the reference panics on length mismatch; here that is H2_EINVAL).
- * Calls are thread-safe and serialise on the device's internal stream (a blocking stream: work enqueued
- * with stream = NULL is ordered against the legacy null stream, PyTorch's default).  One process drives
- * one GPU (h2_init(device)); multi-GPU column sharding is done by the host layer over
- * torch.distributed/RCCL, one rank per GPU.
+ *
+ * Threading and streams.  Every entry point takes one process-wide lock while it validates and ENQUEUES, so calls
+ * from several host threads are safe.  Host-pointer entry points run on the library's own stream of each device and
+ * return when the result is in host memory.  The *_device entry points enqueue on the caller's `stream` (a
+ * hipStream_t; NULL = the library's stream, a blocking stream, i.e. ordered against the legacy null stream that
+ * PyTorch uses by default) and return without synchronising.  Different calls may use different streams: the
+ * library's scratch arenas (one for the MSM, one for the multi-pass NTT, one for the division / prefix scans)
+ * remember their last user and make the next call on another stream wait for it with an event, so results are
+ * correct whatever streams are mixed; an MSM and an NTT on two streams overlap, two MSMs on two streams serialise.
+ * The caller orders its own producers / consumers of the device buffers it passes, as with any HIP library.
+ *
+ * Devices.  h2_init(device) binds the process to one GPU (one process per GPU under torch.distributed / RCCL is how
+ * the Python host layer scales out).  h2_init_devices(n, ids) gives ONE process several GPUs
+ * (the shape a Rust host linking this library wants): bases are replicated on every device at registration,
+ * h2_msm_batch / h2_ntt_batch shard their columns column j -> device j mod n, h2_msm splits one long MSM by
+ * contiguous point range and adds the n partial sums; results travel as 64/96-byte points through host memory, so
+ * no device-to-device collective is needed inside one process.  *_device entry points act on the context of the
+ * calling thread's current HIP device.
  */
 #ifndef H2HIP_H
 #define H2HIP_H
@@ -44,12 +58,19 @@ typedef enum {
   H2_ENOMEM = -2,   /* host or device allocation failed */
   H2_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
   H2_EHANDLE = -4,  /* unknown or released bases handle */
-  H2_ENOTINIT = -5  /* h2_init has not been called */
+  H2_ENOTINIT = -5, /* h2_init has not been called */
+  H2_EPROOF = -6    /* the product surface (h2_generate_proof / h2_verify_proof ...): malformed input or proof */
 } h2_status_t;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 /* Bind this process to one GPU (HIP device ordinal).  Idempotent for the same device. */
 int h2_init(int device);
+/* One process, several GPUs (SURVEY.md section 8(b) `h2_init(n_devices, ids)`): one context, stream and set of
+ * arenas per listed device.  Idempotent for the same list.  An id may be listed twice (two contexts on one GPU:
+ * how the sharded paths are tested on a one-GPU box). */
+int h2_init_devices(int n_devices, const int* device_ids);
+/* number of contexts, or H2_ENOTINIT */
+int h2_device_count(void);
 int h2_shutdown(void);
 const char* h2_strerror(int status);
 /* Text of the last HIP error seen by this process ("" if none). */
@@ -84,6 +105,16 @@ int h2_msm_batch(h2_curve_t curve, uint64_t bases_handle, const uint64_t* const*
  * (a hipStream_t, NULL = the library's stream); returns without synchronising. */
 int h2_msm_device(h2_curve_t curve, uint64_t bases_handle, const void* d_scalars, size_t n, size_t m,
                   void* d_out_jac, void* stream);
+/* The same over a contiguous RANGE of the registered bases: result_j = sum_{i<n} scalars_j[i] * bases[first_base + i],
+ * columns col_stride elements apart (col_stride >= n).  This is one rank's share of an MSM split by point range over
+ * several GPUs (BASELINE config 4): every rank passes its slice of every column, the
+ * partial sums are all-gathered (96 B each) and added with h2_points_sum_device. */
+int h2_msm_device_range(h2_curve_t curve, uint64_t bases_handle, const void* d_scalars, size_t first_base, size_t n,
+                        size_t col_stride, size_t m, void* d_out_jac, void* stream);
+/* d_out_jac[j] = sum_{g < groups} d_in_jac[g * count + j] for j < count (Jacobian points, device memory): adds the
+ * all-gathered partial sums of a range-split MSM.  d_out_jac must not alias d_in_jac. */
+int h2_points_sum_device(h2_curve_t curve, const void* d_in_jac, size_t groups, size_t count, void* d_out_jac,
+                         void* stream);
 
 /* ---- NTT == best_fft(a, omega, log_n) ---------------------------------------------------
  * In place, natural order in and out, A[i] = sum_j a[j] * omega^(i*j), unscaled, over the

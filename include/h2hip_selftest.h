@@ -35,6 +35,13 @@ int h2_selftest_curve_op_device(int curve, int op, const uint64_t* p, const uint
  * out[4 + W + w] = first bit of window w; out[4 + 2W + w] = width of window w (cap >= 4 + 3W).
  * Returns 0, or a negative value (cap too small / carry out of the top window). */
 int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_for_geometry, uint32_t* out, uint32_t cap);
+/* test hook: cap the entries one sort launch may hold, so that the grouped-columns path of wide batches is reached
+ * at small sizes; 0 restores the default (2^31 - 1). */
+int h2_selftest_set_msm_max_entries(uint64_t limit);
+/* the integer ceiling the MSM kernels are priced against: dependent products of the MSM's working field form
+ * (9 x 29-bit limbs) over `curve`'s base field, every CU busy with `waves_per_simd` waves per SIMD; measured
+ * chip-wide modmul/s (best of three launches).  bench.py reports it as `modmul_ceiling`. */
+int h2_selftest_modmul_rate(int curve, int waves_per_simd, int iters, double* modmul_per_s);
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ golden params fixtures through ParamsKZG.
 * MSM n = 2^24 (config 5's column length; dense and "realistic witness" sparse columns): known answer
   MSM(a, [s^i]G) = (sum_i a_i s^i) G with the scalar from the oracle's eval_polynomial.
 * column groups: a batch whose sort would not fit 32-bit entry indices is run in groups of columns
-  (H2_MSM_MAX_ENTRIES forces that path at a small size) and must equal the ungrouped result.
+  (the h2_selftest_set_msm_max_entries hook forces that path at a small size) and must equal the ungrouped result.
 * config 5's per-GPU shape itself: 8 columns of 2^24 through the column groups, and NTT 2^24 x 2 columns.
 * NTT n = 2^22 (three passes) and the 64-column batch shape of config 5 at reduced n: iNTT(NTT(a)) = n a,
   linearity, and A[0] = sum(a).
@@ -148,7 +148,7 @@ def test_msm_2_24_known_answer(h2):
         bases.release()
 
 
-def test_msm_column_groups_equal_one_launch(h2, monkeypatch):
+def test_msm_column_groups_equal_one_launch(h2):
     import torch
     curve = "bn254"
     cid = O.CURVE_IDS[curve]
@@ -160,17 +160,18 @@ def test_msm_column_groups_equal_one_launch(h2, monkeypatch):
         cols = np.stack([O.synth_scalars(fid, 0x48324D5300000600 + j, n).reshape(n, 4) for j in range(m)])
         whole = bases.msm_batch(list(cols))
         windows = bases.plan()["windows"]
-        monkeypatch.setenv("H2_MSM_MAX_ENTRIES", str(2 * windows * n))      # two columns per launch: groups 2 + 2 + 1
+        L = h2.load()
+        L.h2_selftest_set_msm_max_entries(2 * windows * n)                  # two columns per launch: groups 2 + 2 + 1
         grouped = bases.msm_batch(list(cols))
         dev = torch.from_numpy(cols.view(np.int64)).cuda()
         out = torch.zeros((m, 12), dtype=torch.int64, device="cuda")
         bases.msm_device(dev.data_ptr(), n, m, out.data_ptr())
         torch.cuda.synchronize()
-        monkeypatch.setenv("H2_MSM_MAX_ENTRIES", str(windows * n - 1))      # not even one column fits: rejected
+        L.h2_selftest_set_msm_max_entries(windows * n - 1)                  # not even one column fits: rejected
         with pytest.raises(h2.H2Error) as err:
             bases.msm_batch(list(cols))
         assert err.value.status == -1                                       # H2_EINVAL
-        monkeypatch.delenv("H2_MSM_MAX_ENTRIES")
+        L.h2_selftest_set_msm_max_entries(0)
         assert np.array_equal(whole, grouped)
         jac = out.cpu().numpy().view(np.uint64)
         for j in range(m):
