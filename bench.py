@@ -251,34 +251,72 @@ def main():
     n_msm = sum(m for _, m in phases)
     cols_np = splitmix_columns(seed | 1, max(n_msm, 1) * n, p)
     msm_cols = to_dev(cols_np)                # (n_msm*n, 4); every rank holds every column (32 MiB at k = 16)
+    # NTT groups of the step, with what they depend on in a real proof (prover.py / SURVEY.md App. A.4): the
+    # Lagrange -> coefficient -> extended-coset transforms of the advice + instance columns need only the witness, so
+    # they run on a second stream while the commit phases' MSMs run on the first; the two permutation products' start
+    # when phase 2's inputs exist; the quotient's inverse transform needs challenge y, i.e. everything before phase 4
     if args.workload == "poseidon":
-        ntts = [(k, 7, True), (k + ext, 7, False), (k + ext, 1, True)]
+        ntts = [("advice_i", k, 5, True, "side"), ("advice_e", k + ext, 5, False, "side"),
+                ("z_i", k, 2, True, "side_after_phase1"), ("z_e", k + ext, 2, False, "side_after_phase1"),
+                ("h_i", k + ext, 1, True, "main_before_phase3")]
     elif args.workload == "ntt":
-        ntts = [(k, args.ntt_cols, False)]
+        ntts = [("cols", k, args.ntt_cols, False, "main")]
     else:
         ntts = []
-    ntt_bufs = []
-    for j, (lg, m, inv) in enumerate(ntts):
+    ntt_bufs = {}
+    for j, (name, lg, m, inv, _) in enumerate(ntts):
         mine = list(range(rank, m, world))     # NTT columns shard whole: column j -> rank j mod N, no collective
         if mine:
             allc = splitmix_columns(seed | (2 + j), m << lg, p).reshape(m, 1 << lg, 4)
-            ntt_bufs.append((to_dev(np.ascontiguousarray(allc[mine]).reshape(-1, 4)), lg, len(mine), omega(lg, inv)))
+            ntt_bufs[name] = (to_dev(np.ascontiguousarray(allc[mine]).reshape(-1, 4)), lg, len(mine), omega(lg, inv))
     results = [None] * len(phases)
+    side_stream = torch.cuda.Stream(device=dev)
+    side = side_stream.cuda_stream
+    ev_start, ev_phase1, ev_side_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+
+    def run_phase(i, off, mode=None):
+        bases, m = phases[i]
+        results[i] = sharded.msm_phase_device(bases, msm_cols.data_ptr() + off * n * 32, n, m, stream,
+                                              mode=mode if world > 1 else "single")
+        return off + m
 
     def msm_phase(mode=None):
         off = 0
-        for i, (bases, m) in enumerate(phases):
-            results[i] = sharded.msm_phase_device(bases, msm_cols.data_ptr() + off * n * 32, n, m, stream,
-                                                  mode=mode if world > 1 else "single")
-            off += m
+        for i in range(len(phases)):
+            off = run_phase(i, off, mode)
+
+    def run_ntt(name, st):
+        if name in ntt_bufs:
+            buf, lg, m, w = ntt_bufs[name]
+            h2.ntt_device(buf.data_ptr(), m, w, lg, args.curve, st)
 
     def ntt_phase():
-        for buf, lg, m, w in ntt_bufs:
-            h2.ntt_device(buf.data_ptr(), m, w, lg, args.curve, stream)
+        for name, *_ in ntts:
+            run_ntt(name, stream)
 
     def step():
-        msm_phase()
-        ntt_phase()
+        if args.workload != "poseidon":
+            msm_phase()
+            ntt_phase()
+            return
+        # first stream: the five commit phases in Fiat-Shamir order; second stream: the transforms that do not wait
+        # for a challenge
+        ev_start.record(work_stream)
+        side_stream.wait_event(ev_start)
+        off = run_phase(0, 0)
+        ev_phase1.record(work_stream)
+        run_ntt("advice_i", side)
+        run_ntt("advice_e", side)
+        side_stream.wait_event(ev_phase1)       # the permutation products exist once beta, gamma do: after phase 1
+        run_ntt("z_i", side)
+        run_ntt("z_e", side)
+        ev_side_done.record(side_stream)
+        off = run_phase(1, off)
+        off = run_phase(2, off)
+        work_stream.wait_event(ev_side_done)    # y is squeezed after phase 3; the quotient needs every extended column
+        run_ntt("h_i", stream)
+        off = run_phase(3, off)
+        run_phase(4, off)
 
     for _ in range(args.warmup):
         step()
@@ -327,12 +365,19 @@ def main():
         torch.cuda.synchronize()
         phases_ms[name] = round(e0.elapsed_time(e1) / 3, 4)
 
+    overlap = None
+    if args.workload == "poseidon":
+        overlap = {"ms_per_step": round(dt / args.steps * 1e3, 4), "msm_plus_ntt_serial_ms": round(phases_ms["msm"] + phases_ms["ntt"], 4),
+                   "what": "phases_ms times the MSM phases and the NTTs alone, one after the other on one stream; in the "
+                           "step the transforms that wait for no challenge run on a second stream beside the MSMs' "
+                           "small-grid tails (the Fiat-Shamir order of the commit phases is kept)"}
+
     # NTT roofline: algorithmic bytes = m * n * 64 per transform (SURVEY.md 8(d) bytes_ntt: each element read and
     # written once, whatever the number of passes); the per-pass figure the kernels actually move is reported beside it
     roofline_ntt = None
     if ntt_bufs:
-        ntt_bytes = sum(m * (1 << lg) * 64 for _, lg, m, _ in ntt_bufs)
-        pass_bytes = sum(m * (1 << lg) * 64 * ((lg + 9) // 10) for _, lg, m, _ in ntt_bufs)
+        ntt_bytes = sum(m * (1 << lg) * 64 for _, lg, m, _ in ntt_bufs.values())
+        pass_bytes = sum(m * (1 << lg) * 64 * ((lg + 9) // 10) for _, lg, m, _ in ntt_bufs.values())
         ach = ntt_bytes / (phases_ms["ntt"] * 1e-3) / 1e9
         roofline_ntt = {"bound": "hbm", "kernel": "ntt_pass_kernel (all launches of this rank's NTTs of the step)",
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -340,7 +385,7 @@ def main():
                         "algorithmic_bytes_per_step": ntt_bytes, "per_pass_bytes_per_step": pass_bytes,
                         "ms_per_step": phases_ms["ntt"]}
 
-    ops_step = n_msm * ops_msm(n) + sum(m * ops_ntt(1 << lg) for lg, m, _ in ntts)
+    ops_step = n_msm * ops_msm(n) + sum(m * ops_ntt(1 << lg) for _, lg, m, _, _ in ntts)
     value = ops_step * args.steps / dt        # the whole job's field-ops (the same job whatever N) per second
 
     # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read
@@ -398,7 +443,8 @@ def main():
     if not args.no_extras and args.workload == "poseidon":
         for b in (g, g_lagrange):
             b.release()
-        del msm_cols, ntt_bufs
+        del msm_cols
+        ntt_bufs.clear()
         torch.cuda.empty_cache()
         extras["headline_msm_2e20"] = headline_msm(args, 20, make_srs, world, rank, dev, stream, barrier, modmul, p)
         if world > 1:
@@ -435,7 +481,7 @@ def main():
             "sharded_equals_unsharded": sharded_ok,
             "roofline": roofline, "roofline_ntt": roofline_ntt, "modmul_ceiling": modmul,
             "cpu_baseline": cpu, "proof_gen": proof_gen,
-            "phases_ms": phases_ms, "field_ops_per_step": ops_step,
+            "phases_ms": phases_ms, "overlap": overlap, "field_ops_per_step": ops_step,
         }
         out.update(extras)
         print(json.dumps(out))
