@@ -210,7 +210,7 @@ def main():
     ext = 3                                   # Poseidon: degree 6 -> extended_k = k + 3
     # an explicit (non-NULL) stream: the library maps a NULL stream argument to its own stream, and the
     # all-gather below must be ordered after the MSM launches, so everything runs on this one
-    work_stream = torch.cuda.Stream(device=dev)
+    work_stream = torch.cuda.Stream(device=dev, priority=-1)   # the commit phases: ahead of the side stream's transforms
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
     assert stream != 0
@@ -270,7 +270,7 @@ def main():
             allc = splitmix_columns(seed | (2 + j), m << lg, p).reshape(m, 1 << lg, 4)
             ntt_bufs[name] = (to_dev(np.ascontiguousarray(allc[mine]).reshape(-1, 4)), lg, len(mine), omega(lg, inv))
     results = [None] * len(phases)
-    side_stream = torch.cuda.Stream(device=dev)
+    side_stream = torch.cuda.Stream(device=dev, priority=0)
     side = side_stream.cuda_stream
     ev_start, ev_phase1, ev_side_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 

@@ -419,6 +419,7 @@ __global__ void __launch_bounds__(64)
 msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const uint32_t* __restrict__ hot_slot,
                       const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t max_tasks,
                       const uint32_t* __restrict__ head, const uint32_t* __restrict__ tail, uint32_t* __restrict__ hot_part) {
+  __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   const uint32_t ntask = min(*task_count, max_tasks);
   const uint32_t quad = threadIdx.x >> 2;
   for (uint32_t t = blockIdx.x; t < ntask; t += gridDim.x) {
@@ -442,6 +443,7 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
                  const uint32_t* __restrict__ bucket_sum, const uint32_t* __restrict__ head,
                  const uint32_t* __restrict__ tail, const uint32_t* __restrict__ hot_slot,
                  const uint32_t* __restrict__ hot_part, uint32_t* __restrict__ xsum) {
+  __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   const uint32_t G = 1u << log_g;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> log_g;
@@ -477,6 +479,7 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uin
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_weight_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ weighted, size_t K, uint32_t bucket_mask) {
+  __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> 2;
   if (key >= K) return;                       // whole quads leave together (K * 4 threads are launched)
@@ -502,6 +505,7 @@ template <class CV>
 __global__ void __launch_bounds__(64)
 msm_tree_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t count /* per column */,
                     uint32_t seg, uint32_t out_per_col) {
+  __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   const uint32_t col = blockIdx.y;
   const uint32_t base = blockIdx.x * seg;
   const uint32_t end = min(base + seg, count);

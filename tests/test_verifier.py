@@ -153,9 +153,11 @@ def test_accepts_fresh_proofs_made_with_os_randomness(h2):
     proof = prover.wasm_generate_proof(p4, js, 1)
     assert V.wasm_verify_proof(p4, proof, js, 1) is True
     assert V.wasm_verify_proof(p4, proof, ARITH_INPUT, 1) is False
-    js = '{"x":[7,8],"output":"0x00"}'
-    proof = prover.wasm_generate_proof(p6, js, 2)
+    js = '{"x":[7,8],"output":"%s"}' % V.wasm_simulate_circuit('{"x":[7,8]}', 2)   # the prover takes the claimed output
+    proof = prover.wasm_generate_proof(p6, js, 2)                                     # as its public input (wasm.rs:116)
     assert V.wasm_verify_proof(p6, proof, js, 2) is True
+    lie = prover.wasm_generate_proof(p6, '{"x":[7,8],"output":"0x00"}', 2)             # a false claim: no valid proof
+    assert V.wasm_verify_proof(p6, lie, js, 2) is False
     p10 = prover.generate_params(10).write()
     js = '{"x":[6,3,10,5,16,8,4,2,1]}'
     proof = prover.wasm_generate_proof(p10, js, 0)
