@@ -1,7 +1,7 @@
 """Build libh2hip.so in-tree with hipcc for gfx950.
 
-Four translation units: csrc/h2_curve_impl.hip once per curve (-DH2_CURVE_ID=0/1/2; the kernels) and
-csrc/h2_capi.hip (host logic, the C ABI).  They are compiled in parallel and linked into one shared
+Five translation units: csrc/h2_curve_impl.hip once per curve (-DH2_CURVE_ID=0/1/2; the kernels),
+csrc/h2_capi.hip (host logic, the C ABI) and csrc/h2_prover.hip (the product surface: keygen / prove / verify).  They are compiled in parallel and linked into one shared
 library that travels to the GPU box with the repo snapshot.
 """
 import os
@@ -39,6 +39,8 @@ def build(force=False, verbose=False, extra_flags=()):
                      os.path.join(CSRC, "h2_curve_impl.hip"), "-o", obj], obj))
     capi = os.path.join(OBJ, "capi.o")
     jobs.append(([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, "h2_capi.hip"), "-o", capi], capi))
+    prover = os.path.join(OBJ, "prover.o")
+    jobs.append(([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, "h2_prover.hip"), "-o", prover], prover))
 
     def run(job):
         if verbose:
@@ -46,7 +48,7 @@ def build(force=False, verbose=False, extra_flags=()):
         subprocess.check_call(job[0])
         return job[1]
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=5) as ex:
         objs = list(ex.map(run, jobs))
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:

@@ -1,0 +1,228 @@
+// h2_prover_kernels.hpp -- device kernels of the C++ prover (h2_prover.hip), all over bn256::Fr.
+//
+// These are the pieces of halo2_proofs::plonk::create_proof that sit BETWEEN the MSM / NTT calls (SURVEY.md App. A.4,
+// A.7; reached from /root/reference/circuits/src/utils.rs:83-91,105-120): witness columns, the permutation grand
+// product, the quotient numerator, evaluations at the challenge point, the opening combinations.  prover.py runs
+// them as ~600 generic pointwise launches; here each is ONE launch:
+//   * expr_kernel            the whole quotient numerator -- every gate, the permutation argument, the y-fold and the
+//                            division by the vanishing polynomial -- as a straight-line program interpreted per row
+//                            of the extended coset (operands: extended columns with rotations, constants, LDS slots)
+//   * perm_ratio_kernel      prod (v + beta delta^j w^i + gamma) / prod (v + beta sigma_j + gamma) with one inversion
+//                            per 4 rows (Montgomery's trick)
+//   * poly_eval_kernels      all evaluations of a proof (different polynomials at different points) in two launches
+//   * lincomb_kernel         sum_j c_j a_j, up to 24 columns per launch
+//   * coset_extend / coset_shrink   the zero-extension and the zeta^i scaling around the extended-domain NTTs
+// All HBM-bound elementwise work except expr_kernel (a few hundred field products per row).
+#pragma once
+#include "h2_field.hpp"
+
+namespace h2 {
+namespace pk {
+
+using FR = BN254_FR;
+using F = Fe<FR>;
+
+// column[cell.row] = cell.value for `count` cells (values in Montgomery form); the column was zero-filled before
+struct CellRef {
+  uint32_t col, row;
+};
+static __global__ void __launch_bounds__(256)
+scatter_cells_kernel(U128* __restrict__ base, size_t col_stride /* elements */, const CellRef* __restrict__ refs,
+                     const U128* __restrict__ vals, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  U128* dst = base + 2 * ((size_t)refs[i].col * col_stride + refs[i].row);
+  dst[0] = vals[2 * i];
+  dst[1] = vals[2 * i + 1];
+}
+
+// out[c][i] = i < n ? in[c][i] * zeta^i : 0 for i < en   (zeta^3 = 1: the factor is one of three constants)
+static __global__ void __launch_bounds__(256)
+coset_extend_kernel(const U128* __restrict__ in, size_t in_stride, U128* __restrict__ out, uint32_t n, uint32_t en, F z1,
+                    F z2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= en) return;
+  const U128* src = in + 2 * in_stride * blockIdx.y;
+  U128* dst = out + 2 * (size_t)en * blockIdx.y;
+  F v = F::zero();
+  if (i < n) {
+    v = fe_load<FR>(src + 2 * (size_t)i);
+    const uint32_t r = i % 3;
+    if (r == 1) v = fe_mul(v, z1);
+    else if (r == 2) v = fe_mul(v, z2);
+  }
+  fe_store<FR>(dst + 2 * (size_t)i, v);
+}
+// a[i] *= zinv^i in place for i < count (after the inverse extended NTT; only the n (d-1) kept coefficients)
+static __global__ void __launch_bounds__(256) coset_shrink_kernel(U128* __restrict__ a, uint32_t count, F zi1, F zi2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t r = i % 3;
+  if (r == 0) return;
+  F v = fe_load<FR>(a + 2 * (size_t)i);
+  fe_store<FR>(a + 2 * (size_t)i, fe_mul(v, r == 1 ? zi1 : zi2));
+}
+
+// ---- permutation grand product: ratio[i] = prod_j (v_j + beta delta^j w^i + gamma) / prod_j (v_j + beta sigma_j + gamma)
+constexpr int PERM_MAX_COLS = 8;
+constexpr int PERM_RUN = 4;      // rows per thread: one inversion per run (Montgomery's trick)
+struct PermArgs {
+  const U128* value[PERM_MAX_COLS];
+  const U128* sigma[PERM_MAX_COLS];
+  F beta_delta[PERM_MAX_COLS];   // beta * delta^j
+  F beta, gamma;
+  int ncols;
+};
+static __global__ void __launch_bounds__(256)
+perm_ratio_kernel(PermArgs A, const U128* __restrict__ omega_col, U128* __restrict__ ratio, uint32_t n) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = t * PERM_RUN;
+  if (lo >= n) return;
+  F num[PERM_RUN], den[PERM_RUN], pre[PERM_RUN];
+  F acc = F::one();
+#pragma unroll
+  for (int k = 0; k < PERM_RUN; k++) {
+    const uint32_t i = lo + k;
+    F nu = F::one(), de = F::one();
+    if (i < n) {
+      const F w = fe_load<FR>(omega_col + 2 * (size_t)i);
+      for (int j = 0; j < A.ncols; j++) {
+        const F vg = fe_add(fe_load<FR>(A.value[j] + 2 * (size_t)i), A.gamma);
+        nu = fe_mul(nu, fe_add(fe_mul(w, A.beta_delta[j]), vg));
+        de = fe_mul(de, fe_add(fe_mul(fe_load<FR>(A.sigma[j] + 2 * (size_t)i), A.beta), vg));
+      }
+    }
+    num[k] = nu;
+    den[k] = de;
+    pre[k] = acc;
+    acc = fe_mul(acc, de);
+  }
+  F inv = fe_inv(acc);        // a zero denominator (probability 2^-250 per row) would zero the run, as 1/0 := 0 does
+#pragma unroll
+  for (int k = PERM_RUN - 1; k >= 0; k--) {
+    const uint32_t i = lo + k;
+    if (i < n) fe_store<FR>(ratio + 2 * (size_t)i, fe_mul(num[k], fe_mul(pre[k], inv)));
+    inv = fe_mul(inv, den[k]);
+  }
+}
+
+// a[i] = a[i] * c for rows [lo, hi)
+static __global__ void __launch_bounds__(256) scale_range_kernel(U128* __restrict__ a, uint32_t lo, uint32_t hi, F c) {
+  const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  fe_store<FR>(a + 2 * (size_t)i, fe_mul(fe_load<FR>(a + 2 * (size_t)i), c));
+}
+// a[i] -= v[i] for i < count
+static __global__ void sub_prefix_kernel(U128* __restrict__ a, const U128* __restrict__ v, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  fe_store<FR>(a + 2 * (size_t)i, fe_sub(fe_load<FR>(a + 2 * (size_t)i), fe_load<FR>(v + 2 * (size_t)i)));
+}
+
+// ---- out[i] = sum_j c_j a_j[i] ---------------------------------------------------------------------------------
+constexpr int LINCOMB_MAX = 24;
+struct LincombArgs {
+  const U128* a[LINCOMB_MAX];
+  F c[LINCOMB_MAX];
+  int count;
+  int unit_first;   // c[0] == 1: skip its product
+};
+static __global__ void __launch_bounds__(256)
+lincomb_kernel(LincombArgs A, U128* __restrict__ out, uint32_t n, int accumulate) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F acc = accumulate ? fe_load<FR>(out + 2 * (size_t)i) : F::zero();
+  for (int j = 0; j < A.count; j++) {
+    const F v = fe_load<FR>(A.a[j] + 2 * (size_t)i);
+    acc = fe_add(acc, (j == 0 && A.unit_first) ? v : fe_mul(v, A.c[j]));
+  }
+  fe_store<FR>(out + 2 * (size_t)i, acc);
+}
+
+// ---- evaluations: job q = (polynomial pointer, point); partial[q][block] then out[q] ------------------------------
+constexpr int EVAL_RUN = 8;        // coefficients per thread
+constexpr int EVAL_BLOCK = 256;
+struct EvalJob {
+  const U128* poly;
+  F point;
+};
+static __global__ void __launch_bounds__(EVAL_BLOCK)
+poly_eval_partial_kernel(const EvalJob* __restrict__ jobs, uint32_t n, U128* __restrict__ partial, uint32_t blocks_per_job) {
+  __shared__ U128 red[2 * EVAL_BLOCK];
+  const EvalJob job = jobs[blockIdx.y];
+  const uint32_t t = blockIdx.x * EVAL_BLOCK + threadIdx.x;
+  const uint32_t lo = t * EVAL_RUN;
+  F acc = F::zero();
+  if (lo < n) {
+    const uint32_t hi = min(n, lo + EVAL_RUN);
+    for (uint32_t i = hi; i-- > lo;) acc = fe_add(fe_mul(acc, job.point), fe_load<FR>(job.poly + 2 * (size_t)i));
+    acc = fe_mul(acc, fe_pow_u64(job.point, lo));
+  }
+  fe_store<FR>(red + 2 * threadIdx.x, acc);
+  __syncthreads();
+  for (uint32_t s = EVAL_BLOCK / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      fe_store<FR>(red + 2 * threadIdx.x, fe_add(fe_load<FR>(red + 2 * threadIdx.x), fe_load<FR>(red + 2 * (threadIdx.x + s))));
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    U128* dst = partial + 2 * ((size_t)blockIdx.y * blocks_per_job + blockIdx.x);
+    dst[0] = red[0];
+    dst[1] = red[1];
+  }
+}
+static __global__ void __launch_bounds__(64)
+poly_eval_final_kernel(const U128* __restrict__ partial, uint32_t blocks_per_job, U128* __restrict__ out, uint32_t njobs) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= njobs) return;
+  F acc = F::zero();
+  for (uint32_t b = 0; b < blocks_per_job; b++) acc = fe_add(acc, fe_load<FR>(partial + 2 * ((size_t)q * blocks_per_job + b)));
+  fe_store<FR>(out + 2 * (size_t)q, acc);
+}
+
+// ---- the quotient numerator as a straight-line program -----------------------------------------------------------------
+// operand word: bits 31..30 = kind (0 slot, 1 constant, 2 column); slot / constant: index in bits 29..0;
+// column: index in bits 29..8, rotation + 128 in bits 7..0.  op_dst: op in bits 31..24 (0 add, 1 sub, 2 mul), slot in 23..0.
+struct XInstr {
+  uint32_t op_dst, a, b;
+};
+constexpr uint32_t X_SLOT = 0u << 30, X_CONST = 1u << 30, X_COL = 2u << 30;
+constexpr int EXPR_BLOCK = 128;
+
+static __global__ void __launch_bounds__(EXPR_BLOCK)
+expr_kernel(const XInstr* __restrict__ prog, uint32_t ninstr, const U128* const* __restrict__ cols,
+            const uint32_t* __restrict__ col_mask, const U128* __restrict__ consts, U128* __restrict__ out, uint32_t step,
+            uint32_t en) {
+  extern __shared__ uint32_t slots[];     // [slot][limb][thread]
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * EXPR_BLOCK + tid;
+  auto slot_load = [&](uint32_t s) {
+    F r;
+#pragma unroll
+    for (int l = 0; l < 8; l++) r.v[l] = slots[(s * 8 + l) * EXPR_BLOCK + tid];
+    return r;
+  };
+  auto operand = [&](uint32_t code) -> F {
+    const uint32_t kind = code & (3u << 30);
+    if (kind == X_SLOT) return slot_load(code & 0x3FFFFFFFu);
+    if (kind == X_CONST) return fe_load<FR>(consts + 2 * (size_t)(code & 0x3FFFFFFFu));
+    const uint32_t c = (code >> 8) & 0x3FFFFFu;
+    const int rot = (int)(code & 0xFFu) - 128;
+    const uint32_t idx = (i + (uint32_t)(rot * (int)step)) & col_mask[c];
+    return fe_load<FR>(cols[c] + 2 * (size_t)idx);
+  };
+  F r = F::zero();
+  for (uint32_t k = 0; k < ninstr; k++) {
+    const XInstr ins = prog[k];
+    const F a = operand(ins.a), b = operand(ins.b);
+    const uint32_t op = ins.op_dst >> 24;
+    r = op == 0 ? fe_add(a, b) : op == 1 ? fe_sub(a, b) : fe_mul(a, b);
+    const uint32_t s = ins.op_dst & 0xFFFFFFu;
+#pragma unroll
+    for (int l = 0; l < 8; l++) slots[(s * 8 + l) * EXPR_BLOCK + tid] = r.v[l];
+  }
+  if (i < en) fe_store<FR>(out + 2 * (size_t)i, r);     // a domain smaller than one block: the spare lanes computed on wrapped rows
+}
+
+}  // namespace pk
+}  // namespace h2

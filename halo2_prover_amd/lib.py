@@ -60,6 +60,11 @@ SYMBOLS = {
     "h2_msm_plan": (_I, [_U64, ctypes.POINTER(MsmPlan)]),
     "h2_srs_generate": (_I, [_I, _P, _Z, _P, _P]),
     "h2_fixed_base_mul": (_I, [_I, _P, _Z, _P, _P]),
+    "h2_setup": (_I, [_U32, _P, _P, _P, _Z, ctypes.POINTER(_Z)]),
+    "h2_generate_proof": (_I, [_P, _Z, ctypes.c_char_p, _I, _P, _P, _P, _Z, ctypes.POINTER(_Z)]),
+    "h2_verify_proof": (_I, [_P, _Z, _P, _Z, ctypes.c_char_p, _I, ctypes.POINTER(_I)]),
+    "h2_simulate": (_I, [ctypes.c_char_p, _I, _P, _Z, ctypes.POINTER(_Z)]),
+    "h2_circuit_count": (_I, []),
     "h2_profile_enable": (_I, [_I]),
     "h2_profile_read": (_I, [ctypes.POINTER(Profile)]),
 }
@@ -72,7 +77,11 @@ SELFTEST_SYMBOLS = {
     "h2_selftest_curve_op_device": (_I, [_I, _I, _P, _P, _P, _Z]),
     "h2_selftest_set_msm_max_entries": (_I, [_U64]),
     "h2_selftest_modmul_rate": (_I, [_I, _I, _I, ctypes.POINTER(ctypes.c_double)]),
+    "h2_selftest_host": (_I, [_I, _P, _Z, _P, _Z, ctypes.POINTER(_Z)]),
 }
+
+# the RNG callback of the product surface: void (*)(void* ctx, uint8_t* out, size_t n)
+RNG_FILL = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 
 _lib = None
 

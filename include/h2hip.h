@@ -190,6 +190,33 @@ typedef struct {
 int h2_profile_enable(int on);
 int h2_profile_read(h2_profile_t* out);
 
+/* ---- the product surface: setup / prove / verify / simulate / count -----------------------------------
+ * C counterparts of the reference's five wasm-bindgen exports (/root/reference/circuits/src/wasm.rs:49 setup,
+ * :68 wasm_simulate_circuit, :77 wasm_generate_proof, :125 wasm_verify_proof, :182 get_circuit_count), i.e. of
+ * utils.rs:59-158 (generate_params, generate_keys, generate_proof[_with_instance], verify[_with_instance]) over
+ * KZG / BN254 with a Blake2b transcript: circuit 0 = Collatz (SHPLONK, no instance), 1 = arithmetic (GWC, public
+ * inputs [constant, z]), anything else = Poseidon (GWC; prove takes hex_to_fr(output), verify recomputes the hash
+ * of x).  Params and proofs use the reference's wire formats, so artefacts interoperate.
+ * Everything numeric runs on the GPU of the current context; the SRS tables of the last few distinct params blobs
+ * stay registered between calls.
+ *
+ * Randomness comes from the caller, call by call as the reference's RngCore is used: Fr::random = eight calls of
+ * 8 bytes, the blinding polynomial's ChaCha20 seed = one call of 32 bytes.  rng = NULL draws from the OS.  With
+ * the same stream the proof bytes equal the reference's.
+ *
+ * Output buffers are caller-owned; *out_len receives the size (also when the call returns H2_EINVAL because
+ * `cap` is too small).  Malformed params / JSON / proofs give H2_EPROOF (the reference panics); a well-formed
+ * proof that does not verify is *ok = 0 with H2_OK (the reference traps for the GWC circuits, utils.rs:150-157). */
+typedef void (*h2_rng_fill_t)(void* ctx, uint8_t* out, size_t n);
+int h2_setup(uint32_t k, h2_rng_fill_t rng, void* rng_ctx, uint8_t* out, size_t cap, size_t* out_len);
+int h2_generate_proof(const uint8_t* params, size_t params_len, const char* json, int circuit, h2_rng_fill_t rng,
+                      void* rng_ctx, uint8_t* out, size_t cap, size_t* out_len);
+int h2_verify_proof(const uint8_t* params, size_t params_len, const uint8_t* proof, size_t proof_len,
+                    const char* json, int circuit, int* ok);
+/* the NUL-terminated result string of wasm_simulate_circuit ("N/A" for Collatz) */
+int h2_simulate(const char* json, int circuit, char* out, size_t cap, size_t* out_len);
+int h2_circuit_count(void);
+
 #ifdef __cplusplus
 }
 #endif

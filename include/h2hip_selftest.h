@@ -42,6 +42,13 @@ int h2_selftest_set_msm_max_entries(uint64_t limit);
  * (9 x 29-bit limbs) over `curve`'s base field, every CU busy with `waves_per_simd` waves per SIMD; measured
  * chip-wide modmul/s (best of three launches).  bench.py reports it as `modmul_ceiling`. */
 int h2_selftest_modmul_rate(int curve, int waves_per_simd, int iters, double* modmul_per_s);
+/* host-only pieces of the product surface, for the CPU tests (no GPU, no h2_init needed):
+ * what = 0: Blake2b-512 of `in` with the transcript's personalisation ("Halo2-Transcript") -> 64 bytes;
+ * 1: the Poseidon constants over bn256::Fr (68 x 3 round constants, MDS, inverse MDS; 32-byte canonical LE each);
+ * 2 / 3 / 4: circuit 0 / 1 / 2's verifying-key digest for k = in[0] and the commitments in[1..] (64 canonical bytes
+ *    x || y per fixed column then per permutation column, zero = identity) -> 32-byte transcript_repr || the Debug string;
+ * 5: pairing check e(P1, Q1) e(P2, Q2) == 1 on two pairs of 64 + 128 canonical bytes -> one byte. */
+int h2_selftest_host(int what, const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* out_len);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,263 @@
+"""The product surface behind the C ABI (include/h2hip.h: h2_setup / h2_generate_proof / h2_verify_proof / h2_simulate /
+h2_circuit_count), called through ctypes exactly as a Rust or JS host would.
+
+* CPU: the host pieces on their own against the Python mirror (Blake2b, Poseidon constants, the verifying key's Debug
+  string and digest for all three circuits, the pairing, simulate).
+* GPU: under the RNG stream the reference's runs were recorded with the C++ prover reproduces the
+  params files and ALL FIVE recorded proofs byte for byte (arithmetic k=4, Poseidon k=6 / 11 / 16, Collatz k=10 with
+  SHPLONK); the C++ verifier accepts them and rejects corruptions; C++ and Python provers / verifiers accept each
+  other's proofs made with OS randomness; malformed inputs come back as status codes, never as a crash.
+"""
+import ctypes
+import hashlib
+import os
+import random
+
+import pytest
+
+import pyref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ARITH_INPUT = '{"x":6,"y":9,"constant":7,"z":2923}'
+POSEIDON_INPUT = '{"x":[1,2],"output":"0x152e960b5c9c8a624b2cdf4855250e8a54ee074254281310dc4a9704f78c1917"}'
+COLLATZ_SEQ = [9, 28, 14, 7, 22, 11, 34, 17, 52, 26, 13, 40, 20, 10, 5, 16, 8, 4, 2, 1]
+COLLATZ_INPUT = '{"x":%s}' % str(COLLATZ_SEQ).replace(" ", "")
+PARAMS_SHA256 = {4: "e410bf985e9327e7ea474d74907e4209b50678844fab11bc09bcd1e2a2ae1272",
+                 6: "3cd009bb91fe7f1d4c2cc54296263062e5a1d2359aacd68bfa1ce542b5a1169d",
+                 10: "24cef0fa77991930622fce4c51c7ddf40aaf3324779b1c6592c1c29e6043374b",
+                 11: "c071f033c580c8d827fb719c4d428a0d10673b4ab7da0c2ea62dec3ffc3fc6ca",
+                 16: "07d2055cadf19515cc5e2bdc14a46d54b8fccb37e5da5afa2a58cccb0012cee8"}
+PROOF_SHA256 = {("arithmetic", 4): "31d427b9666777794f4a126fbde11584f28748005a32dcaf27e40974f3866f13",
+                ("poseidon", 6): "6d235bf4637e1dce12559c44eaf77812bae2746d78331db3850e16b26234e63e",
+                ("collatz", 10): "8709c25ae65667b14921a4df48907cccc0d7d024ae2f56b2e9e25b6b4d679352",
+                ("poseidon", 11): "8d2d9052b47d9c9b45f3e3c268cec30797f74990cb47367bdfa7fbe77832129c",
+                ("poseidon", 16): "4c4e7d9301b652969a92718b3183f0bda79be2aaab245b68033ca96bf27bdc3c"}
+
+
+def golden(name):
+    return open(os.path.join(GOLDEN, name), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import halo2_prover_amd
+    return halo2_prover_amd.load()
+
+
+class Stream:
+    """the recorded RNG stream as a C callback: one SHA256("seed0-" + counter) digest prefix per call"""
+
+    def __init__(self, start=0):
+        from halo2_prover_amd import lib as h2lib
+        self.s = R.SurveyStream(start=start)
+
+        def fill(_ctx, out, n):
+            data = self.s.fill(n)
+            for i in range(n):
+                out[i] = data[i]
+        self.cb = h2lib.RNG_FILL(fill)
+
+
+def c_setup(L, k, rng):
+    n = ctypes.c_size_t(0)
+    cap = 4 + 128 * (1 << k) + 256
+    out = ctypes.create_string_buffer(cap)
+    rc = L.h2_setup(k, rng.cb if rng else None, None, out, cap, ctypes.byref(n))
+    assert rc == 0, rc
+    return out.raw[:n.value]
+
+
+def c_prove(L, params, js, idx, rng, expect=0):
+    n = ctypes.c_size_t(0)
+    out = ctypes.create_string_buffer(1 << 16)
+    rc = L.h2_generate_proof(params, len(params), js.encode(), idx, rng.cb if rng else None, None, out, 1 << 16, ctypes.byref(n))
+    assert rc == expect, (rc, L.h2_last_device_error())
+    return out.raw[:n.value]
+
+
+def c_verify(L, params, proof, js, idx):
+    ok = ctypes.c_int(-1)
+    rc = L.h2_verify_proof(params, len(params), proof, len(proof), js.encode(), idx, ctypes.byref(ok))
+    return rc, ok.value
+
+
+def host(L, what, data=b"", cap=1 << 20):
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(0)
+    rc = L.h2_selftest_host(what, data, len(data), out, cap, ctypes.byref(n))
+    assert rc == 0, rc
+    return out.raw[:n.value]
+
+
+# ------------------------------------------------------------------------------------------------ CPU ----
+def test_blake2b_matches_hashlib(lib):
+    for msg in (b"", b"abc", b"x" * 127, b"y" * 128, b"z" * 129, b"w" * 1000, bytes(range(256)) * 5):
+        assert host(lib, 0, msg) == hashlib.blake2b(msg, digest_size=64, person=b"Halo2-Transcript").digest()
+
+
+def test_poseidon_constants_match_the_python_mirror(lib):
+    """both restate poseidon/primitives/grain.rs:52-137 and mds.rs:5-102; the Python side is pinned by the recorded
+    Poseidon([1, 2]) output and the proofs"""
+    from halo2_prover_amd import prover
+    rcs, mds, minv = prover._poseidon_constants()
+    raw = host(lib, 1)
+    vals = [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(len(raw) // 32)]
+    want = [v for row in rcs for v in row] + [mds[i][j] for i in range(3) for j in range(3)] + \
+        [minv[i][j] for i in range(3) for j in range(3)]
+    assert vals == want
+
+
+def test_vk_debug_string_and_digest_for_all_three_circuits(lib):
+    from halo2_prover_amd import prover
+    rnd = random.Random(7)
+    for idx, circ, k in ((0, prover.CollatzCircuit([]), 10), (1, prover.ArithmeticCircuit(1, 2, 3), 4),
+                         (2, prover.PoseidonCircuit([1, 2]), 6)):
+        nf, ns = circ.num_fixed, len(circ.permutation_columns)
+        pts = [(rnd.randrange(prover.Q), rnd.randrange(prover.Q)) for _ in range(nf + ns)]
+        pts[nf - 1] = None                                           # an identity commitment prints as "Infinity"
+        data = bytes([k]) + b"".join(b"\0" * 64 if p is None else p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little")
+                                     for p in pts)
+        r = host(lib, 2 + idx, data)
+        s = prover.vk_debug_string(circ, k, pts[:nf], pts[nf:])
+        assert r[32:].decode() == s
+        h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+        h.update(len(s).to_bytes(8, "little"))
+        h.update(s.encode())
+        assert int.from_bytes(r[:32], "little") == int.from_bytes(h.digest(), "little") % prover.P
+
+
+def test_pairing_check_in_c_agrees_with_the_python_pairing(lib):
+    from halo2_prover_amd import pairing as PR
+    from halo2_prover_amd.prover import _G2_GEN, _g2_scalar_mul
+    from test_verifier import _g1_mul
+    q = PR.Q
+
+    def enc(p, g2):
+        return p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little") + \
+            b"".join(v.to_bytes(32, "little") for v in (g2[0][0], g2[0][1], g2[1][0], g2[1][1]))
+    a = 0x123456789ABCDEF0F1E2D3C4B5A69788
+    a_g2 = _g2_scalar_mul(a, _G2_GEN)
+    neg = (a_g2[0], ((-a_g2[1][0]) % q, (-a_g2[1][1]) % q))
+    assert host(lib, 5, enc(_g1_mul(a, (1, 2)), _G2_GEN) + enc((1, 2), neg)) == b"\x01"       # e(aG, H) e(G, -aH) = 1
+    assert host(lib, 5, enc(_g1_mul(a + 1, (1, 2)), _G2_GEN) + enc((1, 2), neg)) == b"\x00"
+    assert PR.pairing_check([(_g1_mul(a, (1, 2)), _G2_GEN), ((1, 2), neg)])
+
+
+def test_simulate_and_count(lib):
+    def sim(js, idx):
+        out = ctypes.create_string_buffer(256)
+        n = ctypes.c_size_t(0)
+        rc = lib.h2_simulate(js.encode(), idx, out, 256, ctypes.byref(n))
+        return rc, out.value.decode()
+    assert lib.h2_circuit_count() == 3
+    assert sim(COLLATZ_INPUT, 0) == (0, "N/A")
+    assert sim(ARITH_INPUT, 1) == (0, "2923")
+    assert sim(POSEIDON_INPUT, 2) == (0, "0x152e960b5c9c8a624b2cdf4855250e8a54ee074254281310dc4a9704f78c1917")
+    assert sim('{"x":4294967296,"y":4294967296,"constant":1}', 1)[0] == -6          # u64 overflow: the reference panics
+    assert sim('{"x":[1]}', 2)[0] == -6
+    assert sim('not json', 1)[0] == -6
+
+
+def test_product_calls_fail_loudly_without_a_gpu(lib):
+    """no CPU fallback: without h2_init the prove / verify / setup entry points return H2_ENOTINIT"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: another test may have initialised the library")
+    n = ctypes.c_size_t(0)
+    out = ctypes.create_string_buffer(4096)
+    assert lib.h2_setup(4, None, None, out, 4096, ctypes.byref(n)) == -5
+    p4 = golden("params_k4.bin")
+    assert lib.h2_generate_proof(p4, len(p4), ARITH_INPUT.encode(), 1, None, None, out, 4096, ctypes.byref(n)) == -5
+
+
+# ------------------------------------------------------------------------------------------------ GPU ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [4, 6, 10, 11])
+def test_c_setup_reproduces_the_recorded_params(h2, lib, k):
+    assert hashlib.sha256(c_setup(lib, k, Stream(0))).hexdigest() == PARAMS_SHA256[k]
+
+
+@pytest.mark.gpu
+def test_c_prover_reproduces_the_recorded_arithmetic_and_poseidon_proofs(h2, lib):
+    proof = c_prove(lib, golden("params_k4.bin"), ARITH_INPUT, 1, Stream(8))
+    assert proof == golden("proof_arithmetic_k4.bin")
+    assert hashlib.sha256(proof).hexdigest() == PROOF_SHA256[("arithmetic", 4)]
+    proof = c_prove(lib, golden("params_k6.bin"), POSEIDON_INPUT, 2, Stream(8))
+    assert proof == golden("proof_poseidon_k6.bin")
+
+
+@pytest.mark.gpu
+def test_c_prover_reproduces_the_recorded_collatz_shplonk_proof(h2, lib):
+    rng = Stream(0)                                   # setup(10) then prove in one process, as recorded
+    params = c_setup(lib, 10, rng)
+    assert hashlib.sha256(params).hexdigest() == PARAMS_SHA256[10]
+    proof = c_prove(lib, params, COLLATZ_INPUT, 0, rng)
+    assert proof == golden("proof_collatz_k10.bin")
+    assert c_verify(lib, params, proof, COLLATZ_INPUT, 0) == (0, 1)
+    bad = bytearray(proof)
+    bad[100] ^= 1
+    assert c_verify(lib, params, bytes(bad), COLLATZ_INPUT, 0) == (0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [11, 16])
+def test_c_prover_reproduces_the_recorded_poseidon_proof_at_baseline_sizes(h2, lib, k):
+    rng = Stream(0)
+    params = c_setup(lib, k, rng)
+    assert hashlib.sha256(params).hexdigest() == PARAMS_SHA256[k]
+    proof = c_prove(lib, params, POSEIDON_INPUT, 2, rng)
+    assert hashlib.sha256(proof).hexdigest() == PROOF_SHA256[("poseidon", k)]
+    assert c_verify(lib, params, proof, POSEIDON_INPUT, 2) == (0, 1)
+    assert c_verify(lib, params, proof, '{"x":[2,1],"output":"0x0"}', 2) == (0, 0)
+
+
+@pytest.mark.gpu
+def test_c_verifier_accepts_the_recorded_proofs_and_rejects_corruptions(h2, lib):
+    for params, proof, js, idx in ((golden("params_k4.bin"), golden("proof_arithmetic_k4.bin"), ARITH_INPUT, 1),
+                                   (golden("params_k6.bin"), golden("proof_poseidon_k6.bin"), POSEIDON_INPUT, 2)):
+        assert c_verify(lib, params, proof, js, idx) == (0, 1)
+        for pos in sorted(set(list(range(0, len(proof), 61)) + [31, 32, len(proof) - 1])):
+            bad = bytearray(proof)
+            bad[pos] ^= 0x02
+            assert c_verify(lib, params, bytes(bad), js, idx) == (0, 0), pos
+        assert c_verify(lib, params, proof[:-32], js, idx) == (0, 0)
+        assert c_verify(lib, params, b"", js, idx) == (0, 0)
+    p4 = golden("params_k4.bin")
+    assert c_verify(lib, p4, golden("proof_arithmetic_k4.bin"), '{"x":6,"y":9,"constant":7,"z":2924}', 1) == (0, 0)
+
+
+@pytest.mark.gpu
+def test_c_and_python_sides_accept_each_others_fresh_proofs(h2, lib):
+    from halo2_prover_amd import prover, verifier as V
+    p4, p6 = golden("params_k4.bin"), golden("params_k6.bin")
+    js = '{"x":3,"y":5,"constant":11,"z":%d}' % (3 * 3 * 5 * 5 + 11)
+    cp = c_prove(lib, p4, js, 1, None)                                  # OS randomness
+    assert len(cp) == 1184 and cp != c_prove(lib, p4, js, 1, None)
+    assert V.wasm_verify_proof(p4, cp, js, 1) is True
+    assert c_verify(lib, p4, prover.wasm_generate_proof(p4, js, 1), js, 1) == (0, 1)
+    js = '{"x":[7,8],"output":"%s"}' % V.wasm_simulate_circuit('{"x":[7,8]}', 2)
+    cp = c_prove(lib, p6, js, 2, None)
+    assert V.wasm_verify_proof(p6, cp, js, 2) is True and c_verify(lib, p6, cp, js, 2) == (0, 1)
+    assert c_verify(lib, p6, prover.wasm_generate_proof(p6, js, 2), js, 2) == (0, 1)
+    p10 = c_setup(lib, 10, None)
+    js = '{"x":[6,3,10,5,16,8,4,2,1]}'
+    cp = c_prove(lib, p10, js, 0, None)
+    assert V.wasm_verify_proof(p10, cp, js, 0) is True and c_verify(lib, p10, cp, js, 0) == (0, 1)
+    assert c_verify(lib, p10, prover.wasm_generate_proof(p10, js, 0), js, 0) == (0, 1)
+
+
+@pytest.mark.gpu
+def test_malformed_inputs_are_status_codes(h2, lib):
+    p4 = golden("params_k4.bin")
+    n = ctypes.c_size_t(0)
+    out = ctypes.create_string_buffer(4096)
+    assert lib.h2_generate_proof(p4[:100], 100, ARITH_INPUT.encode(), 1, None, None, out, 4096, ctypes.byref(n)) == -6
+    assert lib.h2_generate_proof(p4, len(p4), b'{"x":6}', 1, None, None, out, 4096, ctypes.byref(n)) == -6
+    assert lib.h2_generate_proof(p4, len(p4), b'{"x":[1,2],"output":"0x1"}', 2, None, None, out, 4096, ctypes.byref(n)) == -1  # k too small
+    small = ctypes.create_string_buffer(16)
+    assert lib.h2_generate_proof(p4, len(p4), ARITH_INPUT.encode(), 1, None, None, small, 16, ctypes.byref(n)) == -1
+    assert n.value == 1184                                              # how much was needed
+    ok = ctypes.c_int(-1)
+    assert lib.h2_verify_proof(p4, len(p4), b"x", 1, b"{", 1, ctypes.byref(ok)) == -6
+    assert lib.h2_setup(0, None, None, out, 4096, ctypes.byref(n)) == -1
