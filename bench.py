@@ -639,51 +639,86 @@ REFERENCE_PROOF_SHA256 = {6: "6d235bf4637e1dce12559c44eaf77812bae2746d78331db385
 
 
 def proof_generation(k, world=1):
-    """proof-gen ms of the metric: the reference's wasm_generate_proof path (keygen + create_proof, KZG/GWC over
-    BN254) for the Poseidon circuit at 2^k rows on the GPU backend, under the recorded RNG stream so that the
-    proof can be compared with the reference's own (bit-identical <=> equal sha256)."""
+    """proof-gen ms of the metric: the reference's wasm_generate_proof path (ParamsKZG::read + keygen + create_proof,
+    KZG/GWC over BN254) for the Poseidon circuit at 2^k rows, through the C ABI's product surface (h2_setup /
+    h2_generate_proof / h2_verify_proof: C++ orchestration, every column resident in HBM), under the recorded RNG stream
+    so that the proof can be compared with the reference's own (bit-identical <=> equal sha256).  The Python mirror
+    (prover.py, same bytes) is timed beside it."""
     import hashlib
     import torch
+    import halo2_prover_amd as h2
+    from halo2_prover_amd import lib as h2lib
     from halo2_prover_amd import prover
+    L = h2.load()
     rng = _RecordedStream()
+
+    def fill(_ctx, out, n):
+        data = rng.fill(n)
+        for i in range(n):
+            out[i] = data[i]
+    cb = h2lib.RNG_FILL(fill)
+    js = ('{"x":[1,2],"output":"0x%064x"}' % prover.PoseidonCircuit([1, 2]).output()).encode()
+    cap = 4 + 128 * (1 << k) + 256
+    pbuf = ctypes.create_string_buffer(cap)
+    ln = ctypes.c_size_t(0)
     t0 = time.perf_counter()
-    params = prover.generate_params(k, rng)
-    torch.cuda.synchronize()
+    h2lib.check(L.h2_setup(k, cb, None, pbuf, cap, ctypes.byref(ln)), "h2_setup")
     t1 = time.perf_counter()
+    params = pbuf.raw[:ln.value]
     after_setup = rng.counter
-    blob = params.write()
-    del params
+    out = ctypes.create_string_buffer(1 << 16)
     runs = []
-    for _ in range(2):                       # first run: cold (kernel modules load, arenas grow); second: steady state
-        rng.counter = after_setup            # the same draws again, so both runs must give the recorded proof
-        tr = time.perf_counter()
-        params = prover.ParamsKZG.read(blob)   # wasm.rs:79-80: parse + H2D + both MSM tables built (g and g_lagrange)
-        torch.cuda.synchronize()
+    # 0: cold (modules load, params parsed, arenas grow); 1, 2: steady, keys rebuilt on every call as wasm.rs does;
+    # 3: params re-read too; 4, 5, 6: the library's default -- SRS tables and proving key kept between calls
+    L.h2_key_cache(0)
+    for i in range(7):
+        rng.counter = after_setup            # the same draws again: every run must give the recorded proof
+        if i == 3:
+            L.h2_params_cache_clear()
+        if i == 4:
+            L.h2_key_cache(1)
+        ta = time.perf_counter()
+        h2lib.check(L.h2_generate_proof(params, len(params), js, 2, cb, None, out, 1 << 16, ctypes.byref(ln)), "h2_generate_proof")
+        tb = time.perf_counter()
+        runs.append((tb - ta, hashlib.sha256(out.raw[:ln.value]).hexdigest(), ln.value))
+    proof = out.raw[:ln.value]
+    ok = ctypes.c_int(0)
+    tv = time.perf_counter()
+    h2lib.check(L.h2_verify_proof(params, len(params), proof, len(proof), js, 2, ctypes.byref(ok)), "h2_verify_proof")
+    verify_ms = (time.perf_counter() - tv) * 1e3
+    digest, nbytes = runs[1][1], runs[1][2]
+    same = (all(r[1] == REFERENCE_PROOF_SHA256[k] for r in runs)) if k in REFERENCE_PROOF_SHA256 else None
+    # the Python mirror on the same stream (keygen + create_proof, params already parsed)
+    rng.counter = after_setup
+    pparams = prover.ParamsKZG.read(params)
+    mirror = []
+    for _ in range(2):
+        rng.counter = after_setup
         ta = time.perf_counter()
         circuit = prover.PoseidonCircuit([1, 2])
-        pk = prover.generate_keys(params, circuit)
+        pk = prover.generate_keys(pparams, circuit)
+        pproof = prover.generate_proof_with_instance(pparams, pk, circuit, [circuit.output()], rng)
         torch.cuda.synchronize()
-        tb = time.perf_counter()
-        proof = prover.generate_proof_with_instance(params, pk, circuit, [circuit.output()], rng)
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        runs.append((ta - tr, tb - ta, tc - tb, hashlib.sha256(proof).hexdigest(), len(proof)))
-        del pk, params
-    (_, kg0, cp0, d0, _), (rd, kg, cp, digest, nbytes) = runs
-    same = (digest == REFERENCE_PROOF_SHA256[k] and d0 == digest) if k in REFERENCE_PROOF_SHA256 else None
-    return {"circuit": "poseidon (bn254, KZG/GWC)", "k": k, "n_gpus": world,
-            "sharding": "every rank runs the prover; a phase's m commitments are sharded (whole columns when m % N == 0, "
-                        "else point ranges) and all-gathered, 96 B each" if world > 1 else "single GPU",
-            "setup_ms": round((t1 - t0) * 1e3, 1), "params_read_ms": round(rd * 1e3, 1),
-            "keygen_ms": round(kg * 1e3, 1), "create_proof_ms": round(cp * 1e3, 1),
-            "proof_gen_ms": round((kg + cp) * 1e3, 1),
-            "with_params_read_ms": round((rd + kg + cp) * 1e3, 1),
-            "proof_gen_first_call_ms": round((kg0 + cp0) * 1e3, 1),
+        mirror.append((time.perf_counter() - ta, hashlib.sha256(pproof).hexdigest()))
+        del pk
+    del pparams
+    return {"circuit": "poseidon (bn254, KZG/GWC)", "k": k, "n_gpus": world, "through": "C ABI: h2_generate_proof",
+            "setup_ms": round((t1 - t0) * 1e3, 1),
+            "proof_gen_ms": round(min(runs[1][0], runs[2][0]) * 1e3, 2),
+            "create_proof_ms": round(min(runs[5][0], runs[6][0]) * 1e3, 2),
+            "with_params_read_ms": round(runs[3][0] * 1e3, 2),
+            "proof_gen_first_call_ms": round(runs[0][0] * 1e3, 1),
+            "verify_ms": round(verify_ms, 1), "verified": bool(ok.value),
+            "python_mirror_proof_gen_ms": round(mirror[1][0] * 1e3, 1), "python_mirror_same_bytes": mirror[1][1] == digest,
             "proof_bytes": nbytes, "proof_sha256": digest, "bit_identical_to_reference": same,
-            "note": "proof_gen_ms = keygen + create_proof, wall clock with the host side included (witness synthesis, "
-                    "transcript), second call in the process; with_params_read_ms adds ParamsKZG::read as "
-                    "wasm_generate_proof does on every call (parse, H2D, both MSM tables); "
-                    "proof_gen_first_call_ms is the first call (kernel modules loading, arenas growing)"}
+            "note": "proof_gen_ms = one h2_generate_proof call with the key rebuilt as wasm_generate_proof does: JSON, keygen "
+                    "on the empty circuit, witness, create_proof; wall clock, SRS tables resident from an earlier call "
+                    "(best of two steady calls); create_proof_ms = the same call with the library's default key cache "
+                    "(keygen excluded: SURVEY 8(d) asks for both); "
+                    "with_params_read_ms = the same call after h2_params_cache_clear, i.e. with ParamsKZG::read as "
+                    "wasm_generate_proof does on every call (parse, H2D, both MSM tables rebuilt); "
+                    "proof_gen_first_call_ms = first call in the process; verify_ms = h2_verify_proof (re-keygen, "
+                    "transcript, 2 small MSMs, host pairing)"}
 
 
 def cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R):

@@ -350,9 +350,12 @@ int h2_device_count(void) {
   return g_h2.ready ? (int)g_h2.ctx.size() : H2_ENOTINIT;
 }
 
+void h2_prover_shutdown(void);   // h2_prover.hip: keys, params and cached blocks of the product surface
+
 int h2_shutdown(void) {
   std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   if (!g_h2.ready) return H2_OK;
+  h2_prover_shutdown();
   for (size_t i = 0; i < g_h2.ctx.size(); i++) {
     DevCtx& c = g_h2.ctx[i];
     DeviceGuard dg(c.device);

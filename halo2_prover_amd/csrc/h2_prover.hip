@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <functional>
 #include <set>
 
@@ -43,6 +44,21 @@ void hip_ok(hipError_t e, const char* where) {
 void st_ok(int rc, const char* where) {
   if (rc != H2_OK) fail(rc, where);
 }
+
+// phase timings on stderr when H2_TRACE is set (wall clock, the stream is NOT synchronised for the marks)
+struct Trace {
+  bool on;
+  std::chrono::steady_clock::time_point t0, last;
+  const char* what;
+  explicit Trace(const char* w) : on(getenv("H2_TRACE") != nullptr), what(w) { t0 = last = std::chrono::steady_clock::now(); }
+  void mark(const char* phase) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[h2 %s] %-28s %8.3f ms (+%.3f)\n", what, phase, std::chrono::duration<double, std::milli>(now - t0).count(),
+            std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+  }
+};
 
 // ---- the caller's RNG, consumed call by call exactly as the reference's RngCore is -------------------------------
 struct Rng {
@@ -155,8 +171,8 @@ struct Dev {
   std::vector<std::vector<uint8_t>> staged;                   // host buffers of in-flight uploads (kept until sync)
   // size-keyed cache of freed blocks: hipMalloc / hipFree synchronise the device, a proof needs ~60 buffers
   static std::multimap<size_t, void*>& cache() {
-    static std::multimap<size_t, void*> m;
-    return m;
+    static auto* m = new std::multimap<size_t, void*>();   // never destroyed: keys cached until process exit release into it
+    return *m;
   }
   explicit Dev(DevCtx* ctx) : c(ctx), s(ctx->stream), ops(ops_of(H2_BN254)) {}
   void* alloc(size_t bytes) {
@@ -322,8 +338,27 @@ const Params& params_get(const uint8_t* bytes, size_t len) {
   if (k > 28) fail(H2_EPROOF, "params: k out of range");
   const size_t n = (size_t)1 << k;
   if (len != 4 + 128 * n + 256) fail(H2_EPROOF, "params: wrong length for k");
+  // cache key: four interleaved multiply-xorshift lanes over every byte (~10 GB/s; Blake2b took 8 ms on the 8 MiB of
+  // k = 16) finished through Blake2b -- a fingerprint against accidents, not against a caller attacking itself
+  uint64_t lane[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0xD6E8FEB86659FD93ull};
+  {
+    const size_t words = len / 8;
+    const uint8_t* q = bytes;
+    for (size_t i = 0; i + 4 <= words; i += 4, q += 32) {
+      uint64_t w[4];
+      memcpy(w, q, 32);
+      for (int l = 0; l < 4; l++) {
+        lane[l] = (lane[l] ^ w[l]) * 0xFF51AFD7ED558CCDull;
+        lane[l] ^= lane[l] >> 29;
+      }
+    }
+    for (; q < bytes + len; q++) lane[0] = (lane[0] ^ *q) * 0x100000001B3ull;
+  }
   Blake2b h;
-  h.update(bytes, len);
+  h.update(lane, sizeof lane);
+  h.update(&len, sizeof len);
+  h.update(bytes, 4);
+  h.update(bytes + len - 256, 256);
   std::array<uint8_t, 64> dg;
   h.digest(dg.data());
   for (size_t i = 0; i < g_params.size(); i++)
@@ -518,14 +553,30 @@ Fr fr_delta() {   // DELTA = 7^(2^28): generator of the coset structure of the p
 std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange) {
   auto it = g_h2.bases.find(lagrange ? P.h_gl : P.h_g);
   if (it == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
-  void* out = d.alloc(m * 64);
-  st_ok(msm_device_run(*d.c, H2_BN254, it->second, cols, 0, n, n, m, out, true, d.s), "msm_device_run");
-  std::vector<uint8_t> raw(m * 64);
+  void* out = d.alloc(m * 96);
+  st_ok(msm_device_run(*d.c, H2_BN254, it->second, cols, 0, n, n, m, out, false, d.s), "msm_device_run");
+  std::vector<uint8_t> raw(m * 96);
   hip_ok(hipMemcpyAsync(raw.data(), out, raw.size(), hipMemcpyDeviceToHost, d.s), "hipMemcpyAsync(D2H)");
   d.sync();
   d.release(out);
+  // Jacobian -> affine on the host: m inversions folded into one (a one-thread device kernel took 0.35 ms per phase)
+  std::vector<Fq> zs(m), pre(m);
+  Fq acc = Fq::one();
+  for (size_t j = 0; j < m; j++) {
+    zs[j] = Fq::from_mont_limbs(raw.data() + 96 * j + 64);
+    pre[j] = acc;
+    if (!zs[j].is_zero()) acc *= zs[j];
+  }
+  Fq inv = acc.inv();
   std::vector<G1> pts(m);
-  for (size_t j = 0; j < m; j++) pts[j] = affine_from_raw(raw.data() + 64 * j);
+  for (size_t j = m; j-- > 0;) {
+    if (zs[j].is_zero()) continue;                     // identity
+    const Fq zi = inv * pre[j], zi2 = zi.sqr();
+    inv *= zs[j];
+    pts[j].x = Fq::from_mont_limbs(raw.data() + 96 * j) * zi2;
+    pts[j].y = Fq::from_mont_limbs(raw.data() + 96 * j + 32) * zi2 * zi;
+    pts[j].inf = false;
+  }
   return pts;
 }
 
@@ -538,6 +589,7 @@ void coeff_to_extended(Dev& d, const Domain& D, Col in, size_t m, Col out) {
 }
 
 std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> circuit, DevCtx* ctx) {
+  Trace trace("keygen");
   auto pkp = std::make_unique<ProvingKey>();
   ProvingKey& K = *pkp;
   K.params = &P;
@@ -606,7 +658,9 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
     }
   }
   // commitments of the fixed + sigma columns (one MSM phase), their coefficient and extended forms
+  trace.mark("columns built");
   std::vector<G1> commits = commit(d, P, lag, n, nf + np, true);
+  trace.mark("fixed + sigma committed");
   K.fixed_commitments.assign(commits.begin(), commits.begin() + nf);
   K.sigma_commitments.assign(commits.begin() + nf, commits.end());
   Col polys = d.col((nf + np + 3) * n);      // + the three Lagrange basis combinations l0, l_last, l_blind
@@ -642,6 +696,7 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   // vk digest
   const std::string s = vk_debug_string(C, D.k, D.ext_k, D.omega, K.fixed_commitments, K.sigma_commitments);
   K.transcript_repr = vk_transcript_repr(s);
+  trace.mark("vk digest");
 
   // ---- the quotient program ---------------------------------------------------------------------------------------
   ColumnMap& M = K.cmap;
@@ -703,7 +758,10 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   const int root = X.mul(numer, X.column(M.tinv, 0));
   X.compile(root);
   K.d_code = (const pk::XInstr*)d.upload(X.code.data(), X.code.size() * sizeof(pk::XInstr));
+  trace.mark("program compiled");
   d.sync();
+  trace.mark("synchronised");
+  if (trace.on) fprintf(stderr, "[h2 keygen] quotient program: %zu instructions, %u slots, %zu constants\n", X.code.size(), X.nslots, X.consts.size());
   return pkp;
 }
 
@@ -716,7 +774,8 @@ struct Query {
 
 void shplonk_open(Transcript& tr, Dev& d, const Params& P, uint32_t n, const std::vector<Query>& queries);
 
-std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<Fr>& public_input, Rng& rng, bool shplonk) {
+std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::vector<Fr>& public_input, Rng& rng, bool shplonk) {
+  Trace trace("prove");
   const Domain& D = *K.dom;
   const Params& P = *K.params;
   Dev d(K.dev->c);
@@ -746,7 +805,9 @@ std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<F
     for (size_t j = 0; j < adv.size(); j++) (void)rng.fr_random();       // the Blind of each commitment (unused by KZG)
     d.fill_sparse(advice_values, n, adv);
   }
+  trace.mark("witness uploaded");
   for (auto& pt : commit(d, P, advice_values, n, na, true)) tr.write_point(pt);
+  trace.mark("advice committed");
   const Fr theta = tr.squeeze_challenge(), beta = tr.squeeze_challenge(), gamma = tr.squeeze_challenge();
   (void)theta;
 
@@ -757,28 +818,39 @@ std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<F
     if (cr.first == FIXED) return K.fixed_values + 2 * (size_t)cr.second * n;
     return instance_values + 2 * (size_t)cr.second * n;
   };
-  {
-    Fr last_z = Fr::one();
-    Col ratio = d.col(n);
-    for (size_t si = 0; si < nz; si++) {
-      pk::PermArgs A{};
-      A.ncols = (int)K.sets[si].size();
-      if (A.ncols > pk::PERM_MAX_COLS) fail(H2_EINVAL, "permutation set too wide");
-      for (int t = 0; t < A.ncols; t++) {
-        const int j = K.sets[si][t];
-        A.value[t] = values_of(C.permutation_columns[j]);
-        A.sigma[t] = K.sigma_values + 2 * (size_t)j * n;
-        A.beta_delta[t] = (beta * delta.pow_u64((uint64_t)j)).v;
+  if (nz) {
+    // every set's ratio column in ONE launch sequence (they only need beta and gamma), then one read-back of the
+    // sets' last usable products: z_i = (prod_{s < i} tail_s) * prefix_i, blinding rows drawn set by set
+    Col ratio = d.col(nz * (size_t)n);
+    for (size_t s0 = 0; s0 < nz; s0 += pk::PERM_MAX_SETS) {
+      const size_t cnt = std::min<size_t>(pk::PERM_MAX_SETS, nz - s0);
+      pk::PermBatch B{};
+      for (size_t q = 0; q < cnt; q++) {
+        pk::PermArgs& A = B.set[q];
+        const size_t si = s0 + q;
+        A.ncols = (int)K.sets[si].size();
+        if (A.ncols > pk::PERM_MAX_COLS) fail(H2_EINVAL, "permutation set too wide");
+        for (int t = 0; t < A.ncols; t++) {
+          const int j = K.sets[si][t];
+          A.value[t] = values_of(C.permutation_columns[j]);
+          A.sigma[t] = K.sigma_values + 2 * (size_t)j * n;
+          A.beta_delta[t] = (beta * delta.pow_u64((uint64_t)j)).v;
+        }
+        A.beta = beta.v;
+        A.gamma = gamma.v;
       }
-      A.beta = beta.v;
-      A.gamma = gamma.v;
-      hipLaunchKernelGGL(pk::perm_ratio_kernel, dim3((n / pk::PERM_RUN + 255) / 256 + 1), dim3(256), 0, d.s, A, K.omega_col,
-                         ratio, n);
+      hipLaunchKernelGGL(pk::perm_ratio_kernel, dim3((n / pk::PERM_RUN + 255) / 256 + 1, (unsigned)cnt), dim3(256), 0, d.s, B,
+                         K.omega_col, ratio + 2 * s0 * (size_t)n, n);
       hip_ok(hipGetLastError(), "perm_ratio_kernel");
+    }
+    for (size_t si = 0; si < nz; si++) d.prefix_product(ratio + 2 * si * (size_t)n, n, z_values + 2 * si * (size_t)n);
+    // the products over the usable rows (row n - bf - 1 of every prefix column): one gather, one copy back
+    Col tails_d = d.col(nz);
+    for (size_t si = 0; si < nz; si++) d.copy(tails_d + 2 * si, z_values + 2 * (si * (size_t)n + (n - bf - 1)), 32);
+    const std::vector<Fr> tails = d.download_frs(tails_d, nz);
+    Fr last_z = Fr::one();
+    for (size_t si = 0; si < nz; si++) {
       Col z = z_values + 2 * si * (size_t)n;
-      d.prefix_product(ratio, n, z);
-      // the product over the usable rows, before scaling: the next set starts from there
-      const Fr tail = d.download_frs(z + 2 * (size_t)(n - bf - 1), 1)[0];
       if (!(last_z == Fr::one())) {
         hipLaunchKernelGGL(pk::scale_range_kernel, dim3((n + 255) / 256), dim3(256), 0, d.s, z, 0u, n, last_z.v);
         hip_ok(hipGetLastError(), "scale_range_kernel");
@@ -787,13 +859,15 @@ std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<F
       for (int t = 0; t < bf; t++) blind[t] = rng.fr_random();
       Col d_blind = d.upload_frs(blind);
       d.copy(z + 2 * (size_t)(n - bf), d_blind, (size_t)bf * 32);
-      last_z = last_z * tail;
+      last_z = last_z * tails[si];
       (void)rng.fr_random();
     }
     d.release(ratio);
   }
+  trace.mark("grand products built");
   if (nz)
     for (auto& pt : commit(d, P, z_values, n, nz, true)) tr.write_point(pt);
+  trace.mark("grand products committed");
 
   // the vanishing argument's random polynomial: one ChaCha20 seed, n sequential draws
   Col random_poly = d.col(n);
@@ -806,6 +880,7 @@ std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<F
     (void)rng.fr_random();
   }
   tr.write_point(commit(d, P, random_poly, n, 1, false)[0]);
+  trace.mark("random poly committed");
 
   // coefficient forms, then the extended coset
   Col polys = d.col((na + ni + nz) * (size_t)n);
@@ -855,7 +930,9 @@ std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<F
                      D.zeta_inv.sqr().v);
   hip_ok(hipGetLastError(), "coset_shrink_kernel");
   Col h_pieces = h_ext;                       // deg - 1 pieces of n coefficients, contiguous
+  trace.mark("quotient enqueued");
   for (auto& pt : commit(d, P, h_pieces, n, (size_t)(deg - 1), false)) tr.write_point(pt);
+  trace.mark("quotient committed");
   for (int t = 0; t < deg - 1; t++) (void)rng.fr_random();
 
   // evaluations at x
@@ -888,6 +965,7 @@ std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<F
   if (shplonk) jobs.push_back({h_poly, x});
   const std::vector<Fr> evals = d.evaluate(jobs, n);
   for (size_t i = 0; i < wanted.size(); i++) tr.write_scalar(evals[i]);
+  trace.mark("evaluations");
   std::map<std::pair<Col, std::array<uint8_t, 32>>, Fr> eval_of;
   auto key_of = [](Col c, const Fr& pt) {
     std::array<uint8_t, 32> b;
@@ -935,6 +1013,7 @@ std::vector<uint8_t> create_proof(ProvingKey& K, Circuit& C, const std::vector<F
     d.divide_linear(acc, n, points[pi], witnesses + 2 * pi * (size_t)n);
   }
   for (auto& pt : commit(d, P, witnesses, n, points.size(), false)) tr.write_point(pt);
+  trace.mark("openings committed");
   return tr.bytes();
 }
 
@@ -1450,6 +1529,40 @@ bn::G2 g2_mul(const Fr& k, const bn::G2& pt) {
   return r;
 }
 
+// proving keys kept between calls (the reference rebuilds them on every prove and verify, wasm.rs:86,95,114,132;
+// a key depends only on the params and the circuit's fixed columns): keyed by params digest and circuit index
+struct KeyEntry {
+  std::array<uint8_t, 64> digest;
+  int circuit;
+  std::unique_ptr<ProvingKey> key;
+};
+std::vector<KeyEntry> g_keys;
+bool g_key_cache = true;
+
+std::unique_ptr<Circuit> empty_circuit(int idx) {
+  if (idx == 0) return std::make_unique<CollatzCircuit>();
+  if (idx == 1) return std::make_unique<ArithmeticCircuit>();
+  return std::make_unique<PoseidonCircuit>();
+}
+int circuit_slot(int idx) { return idx == 0 ? 0 : idx == 1 ? 1 : 2; }
+
+// the key for (params, circuit): cached or built now; `owner` keeps a freshly built uncached key alive
+ProvingKey& key_for(const Params& P, int idx, DevCtx* ctx, std::unique_ptr<ProvingKey>& owner) {
+  const int slot = circuit_slot(idx);
+  if (g_key_cache) {
+    for (auto& e : g_keys)
+      if (e.circuit == slot && e.digest == P.digest) {
+        e.key->params = &P;       // the params list may have been reordered since
+        return *e.key;
+      }
+  }
+  owner = keygen(P, empty_circuit(slot), ctx);
+  if (!g_key_cache) return *owner;
+  if (g_keys.size() >= 6) g_keys.erase(g_keys.begin());
+  g_keys.push_back({P.digest, slot, std::move(owner)});
+  return *g_keys.back().key;
+}
+
 DevCtx* the_ctx() {
   if (!g_h2.ready) fail(H2_ENOTINIT, "h2_init has not been called");
   DevCtx* c = ctx_current();
@@ -1617,13 +1730,12 @@ int h2_generate_proof(const uint8_t* params, size_t params_len, const char* json
     const Params& P = params_get(params, params_len);
     const Json js(json);
     Job job = job_for_proof(js, circuit);
-    Circuit* C = job.circuit.get();
-    // keygen on every call, as wasm.rs:86,95,114 does (the key is rebuilt from the empty circuit's fixed columns)
-    std::unique_ptr<Circuit> owned = std::move(job.circuit);
-    std::unique_ptr<ProvingKey> K = keygen(P, std::move(owned), ctx);
+    // the key comes from the EMPTY circuit (wasm.rs:86,95,114 rebuild it on every call; here it is kept, see
+    // h2_key_cache), the witness from the JSON
+    std::unique_ptr<ProvingKey> owner;
+    ProvingKey& K = key_for(P, circuit, ctx, owner);
     Rng rng{rng_fn, rng_ctx};
-    const std::vector<uint8_t> proof = create_proof(*K, *K->circuit, job.public_input, rng, job.shplonk);
-    (void)C;
+    const std::vector<uint8_t> proof = create_proof(K, *job.circuit, job.public_input, rng, job.shplonk);
     return emit(proof, out, cap, out_len);
   });
 }
@@ -1637,10 +1749,45 @@ int h2_verify_proof(const uint8_t* params, size_t params_len, const uint8_t* pro
     const Params& P = params_get(params, params_len);
     const Json js(json);
     Job job = job_for_verify(js, circuit);
-    std::unique_ptr<ProvingKey> K = keygen(P, std::move(job.circuit), ctx);
-    *ok = verify_proof(*K, proof, proof_len, job.public_input, job.shplonk) ? 1 : 0;
+    std::unique_ptr<ProvingKey> owner;
+    ProvingKey& K = key_for(P, circuit, ctx, owner);
+    *ok = verify_proof(K, proof, proof_len, job.public_input, job.shplonk) ? 1 : 0;
     return H2_OK;
   });
+}
+
+// forget the resident SRS tables (the next call with any params blob parses and registers it again)
+int h2_params_cache_clear(void) {
+  return guarded([&]() -> int {
+    g_keys.clear();                                   // keys point into the params list
+    for (auto& p : g_params) {
+      (void)h2_bases_release(p.h_g);
+      (void)h2_bases_release(p.h_gl);
+    }
+    g_params.clear();
+    return H2_OK;
+  });
+}
+
+// called by h2_shutdown: drop keys, params and the cached device blocks
+void h2_prover_shutdown(void) {
+  g_keys.clear();
+  for (auto& p : g_params) {
+    (void)h2_bases_release(p.h_g);
+    (void)h2_bases_release(p.h_gl);
+  }
+  g_params.clear();
+  for (auto& kv : Dev::cache()) (void)hipFree(kv.second);
+  Dev::cache().clear();
+}
+
+// keep proving keys between calls (default) or rebuild them on every call as the reference does; returns the old setting
+int h2_key_cache(int enable) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  const int old = g_key_cache ? 1 : 0;
+  g_key_cache = enable != 0;
+  if (!g_key_cache) g_keys.clear();
+  return old;
 }
 
 // host-side pieces exposed for the CPU tests (no GPU needed): the vk digest of a circuit for given commitments, the

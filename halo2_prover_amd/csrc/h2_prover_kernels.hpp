@@ -73,8 +73,15 @@ struct PermArgs {
   F beta, gamma;
   int ncols;
 };
+constexpr int PERM_MAX_SETS = 4;
+struct PermBatch {
+  PermArgs set[PERM_MAX_SETS];
+};
+// grid.y = permutation set (the sets only share beta and gamma: all of them in one launch); ratio: one column per set
 static __global__ void __launch_bounds__(256)
-perm_ratio_kernel(PermArgs A, const U128* __restrict__ omega_col, U128* __restrict__ ratio, uint32_t n) {
+perm_ratio_kernel(PermBatch B, const U128* __restrict__ omega_col, U128* __restrict__ ratio_base, uint32_t n) {
+  const PermArgs& A = B.set[blockIdx.y];
+  U128* ratio = ratio_base + 2 * (size_t)n * blockIdx.y;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lo = t * PERM_RUN;
   if (lo >= n) return;

@@ -65,6 +65,8 @@ SYMBOLS = {
     "h2_verify_proof": (_I, [_P, _Z, _P, _Z, ctypes.c_char_p, _I, ctypes.POINTER(_I)]),
     "h2_simulate": (_I, [ctypes.c_char_p, _I, _P, _Z, ctypes.POINTER(_Z)]),
     "h2_circuit_count": (_I, []),
+    "h2_params_cache_clear": (_I, []),
+    "h2_key_cache": (_I, [_I]),
     "h2_profile_enable": (_I, [_I]),
     "h2_profile_read": (_I, [ctypes.POINTER(Profile)]),
 }

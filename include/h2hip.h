@@ -216,6 +216,14 @@ int h2_verify_proof(const uint8_t* params, size_t params_len, const uint8_t* pro
 /* the NUL-terminated result string of wasm_simulate_circuit ("N/A" for Collatz) */
 int h2_simulate(const char* json, int circuit, char* out, size_t cap, size_t* out_len);
 int h2_circuit_count(void);
+/* The SRS of the last few distinct params blobs stays registered (MSM tables resident in HBM) between calls; this
+ * releases them: the next call parses and registers its params again, as the reference does on every call. */
+int h2_params_cache_clear(void);
+/* Proving keys (fixed + permutation columns in all their forms, their commitments, the vk digest, the compiled
+ * quotient program) depend only on the params and the circuit index; the reference rebuilds them on every prove and
+ * verify call (wasm.rs:86,95,114,132), this library keeps them by default.  h2_key_cache(0) restores the
+ * reference's behaviour (bench.py times both); returns the previous setting. */
+int h2_key_cache(int enable);
 
 #ifdef __cplusplus
 }
