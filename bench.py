@@ -256,9 +256,10 @@ def main():
     # they run on a second stream while the commit phases' MSMs run on the first; the two permutation products' start
     # when phase 2's inputs exist; the quotient's inverse transform needs challenge y, i.e. everything before phase 4
     if args.workload == "poseidon":
-        ntts = [("advice_i", k, 5, True, "side"), ("advice_e", k + ext, 5, False, "side"),
-                ("z_i", k, 2, True, "side_after_phase1"), ("z_e", k + ext, 2, False, "side_after_phase1"),
-                ("h_i", k + ext, 1, True, "main_before_phase3")]
+        ntts = [("advice_i", k, 5, True, "beside tail 0"), ("advice_e_a", k + ext, 2, False, "beside tail 0"),
+                ("advice_e_b", k + ext, 3, False, "beside tail 1"),
+                ("z_i", k, 2, True, "beside tail 2"), ("z_e", k + ext, 2, False, "beside tail 2"),
+                ("h_i", k + ext, 1, True, "main stream, before phase 3")]
     elif args.workload == "ntt":
         ntts = [("cols", k, args.ntt_cols, False, "main")]
     else:
@@ -272,7 +273,7 @@ def main():
     results = [None] * len(phases)
     side_stream = torch.cuda.Stream(device=dev, priority=0)
     side = side_stream.cuda_stream
-    ev_start, ev_phase1, ev_side_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+    ev_start, ev_side_done = torch.cuda.Event(), torch.cuda.Event()
 
     def run_phase(i, off, mode=None):
         bases, m = phases[i]
@@ -299,21 +300,24 @@ def main():
             msm_phase()
             ntt_phase()
             return
-        # first stream: the five commit phases in Fiat-Shamir order; second stream: the transforms that do not wait
-        # for a challenge
+        # first stream: the five commit phases in Fiat-Shamir order.  Second stream: the transforms that wait for no
+        # challenge, each group queued behind the accumulate kernel of a commit phase (h2_stream_wait_msm_tail), so
+        # that it runs beside that phase's small-grid tail instead of beside its chip-filling kernel
         ev_start.record(work_stream)
         side_stream.wait_event(ev_start)
         off = run_phase(0, 0)
-        ev_phase1.record(work_stream)
+        L.h2_stream_wait_msm_tail(side)
         run_ntt("advice_i", side)
-        run_ntt("advice_e", side)
-        side_stream.wait_event(ev_phase1)       # the permutation products exist once beta, gamma do: after phase 1
+        run_ntt("advice_e_a", side)
+        off = run_phase(1, off)                 # the permutation products exist once beta, gamma do: after phase 0
+        L.h2_stream_wait_msm_tail(side)
+        run_ntt("advice_e_b", side)
+        off = run_phase(2, off)
+        L.h2_stream_wait_msm_tail(side)
         run_ntt("z_i", side)
         run_ntt("z_e", side)
         ev_side_done.record(side_stream)
-        off = run_phase(1, off)
-        off = run_phase(2, off)
-        work_stream.wait_event(ev_side_done)    # y is squeezed after phase 3; the quotient needs every extended column
+        work_stream.wait_event(ev_side_done)    # y is squeezed after phase 2; the quotient needs every extended column
         run_ntt("h_i", stream)
         off = run_phase(3, off)
         run_phase(4, off)

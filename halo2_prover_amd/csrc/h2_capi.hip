@@ -10,10 +10,45 @@
 #include <cstdio>
 #include <cstring>
 
+#include "h2_host.hpp"
 #include "h2_ntt.hpp"
 #include "h2_poly.hpp"
 
 using namespace h2;
+
+namespace {
+// m Jacobian points (96 B, Montgomery limbs) -> m affine points (64 B, identity = (0, 0)) on the host, the m inversions
+// folded into one: the one-thread-per-point device kernel this replaces took 0.35 ms of pure latency per call
+template <class FP>
+void jac_to_affine_host(const uint8_t* jac, size_t m, uint8_t* out) {
+  using H = HF<FP>;
+  std::vector<H> z(m), pre(m);
+  H acc = H::one();
+  for (size_t j = 0; j < m; j++) {
+    z[j] = H::from_mont_limbs(jac + 96 * j + 64);
+    pre[j] = acc;
+    if (!z[j].is_zero()) acc *= z[j];
+  }
+  H inv = acc.inv();
+  for (size_t j = m; j-- > 0;) {
+    uint8_t* o = out + 64 * j;
+    if (z[j].is_zero()) {
+      memset(o, 0, 64);
+      continue;
+    }
+    const H zi = inv * pre[j], zi2 = zi.sqr();
+    inv *= z[j];
+    const H x = H::from_mont_limbs(jac + 96 * j) * zi2, y = H::from_mont_limbs(jac + 96 * j + 32) * zi2 * zi;
+    memcpy(o, x.v.v, 32);
+    memcpy(o + 32, y.v.v, 32);
+  }
+}
+void jac_to_affine_host(int curve, const uint8_t* jac, size_t m, uint8_t* out) {
+  if (curve == H2_BN254) jac_to_affine_host<BN254_FQ>(jac, m, out);
+  else if (curve == H2_PALLAS) jac_to_affine_host<PASTA_FP>(jac, m, out);
+  else jac_to_affine_host<PASTA_FQ>(jac, m, out);
+}
+}  // namespace
 
 namespace h2 {
 
@@ -183,8 +218,10 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
         c.prof_alg_bytes += (double)mm * (double)n * 96.0 + (double)mm * 96.0;  // SURVEY.md 8(d) bytes_msm
       }
     }
+    if (c.tail_wanted && !c.tail_event) H2_TRY(hipEventCreateWithFlags(&c.tail_event, hipEventDisableTiming));
     hipError_t e = ops->msm_launch(table, (uint32_t)be.n, (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
-                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1);
+                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1, c.tail_wanted ? c.tail_event : nullptr);
+    c.tail_recorded = c.tail_wanted;
     if (e != hipSuccess) return dev_fail(e, "msm_launch");
     const void* src = (char*)c.msm_ws.p + ws.off_tree2;
     void* dst = (char*)d_out + j0 * out_sz;
@@ -457,6 +494,15 @@ int h2_msm_device(h2_curve_t curve, uint64_t handle, const void* d_scalars, size
   return h2_msm_device_range(curve, handle, d_scalars, 0, n, n, m, d_out_jac, stream_);
 }
 
+int h2_stream_wait_msm_tail(void* stream_) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
+  if (k.c->tail_recorded) H2_TRY(hipStreamWaitEvent(k.stream, k.c->tail_event, 0));
+  k.c->tail_wanted = true;          // from now on every MSM of this context marks the end of its accumulate kernel
+  return H2_OK;
+}
+
 int h2_points_sum_device(h2_curve_t curve, const void* d_in_jac, size_t groups, size_t count, void* d_out_jac,
                          void* stream_) {
   std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
@@ -523,7 +569,10 @@ static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* co
     H2_TRY(hipStreamSynchronize(c.stream));
     return H2_OK;
   }
-  // column sharding: context g takes columns g, g + G, ...
+  // column sharding: context g takes columns g, g + G, ...; the results come back as Jacobian points and are
+  // normalised on the host when the caller wants affine ones
+  std::vector<uint8_t> jac(affine_out ? m * 96 : 0);
+  uint8_t* dst = affine_out ? jac.data() : (uint8_t*)out;
   for (size_t g = 0; g < G && g < m; g++) {
     DevCtx& c = g_h2.ctx[g];
     DeviceGuard dg(c.device);
@@ -535,16 +584,20 @@ static int msm_host(h2_curve_t curve, uint64_t handle, const uint64_t* const* co
       H2_TRY(hipMemcpyAsync((char*)c.stage.p + i * col_bytes, cols[g + i * G], col_bytes, hipMemcpyHostToDevice,
                             c.stream));
     void* d_res = (char*)c.stage.p + res_off;
-    rc = msm_device_run(c, (int)curve, *be, c.stage.p, 0, n, n, mine, d_res, affine_out, c.stream);
+    rc = msm_device_run(c, (int)curve, *be, c.stage.p, 0, n, n, mine, d_res, false, c.stream);
     if (rc != H2_OK) return rc;
-    for (size_t i = 0; i < mine; i++)
-      H2_TRY(hipMemcpyAsync((char*)out + (g + i * G) * out_sz, (char*)d_res + i * out_sz, out_sz,
-                            hipMemcpyDeviceToHost, c.stream));
+    if (G == 1) {
+      H2_TRY(hipMemcpyAsync(dst, d_res, mine * 96, hipMemcpyDeviceToHost, c.stream));
+    } else {
+      for (size_t i = 0; i < mine; i++)
+        H2_TRY(hipMemcpyAsync(dst + (g + i * G) * 96, (char*)d_res + i * 96, 96, hipMemcpyDeviceToHost, c.stream));
+    }
   }
   for (size_t g = 0; g < G && g < m; g++) {
     DeviceGuard dg(g_h2.ctx[g].device);
     H2_TRY(hipStreamSynchronize(g_h2.ctx[g].stream));
   }
+  if (affine_out) jac_to_affine_host((int)curve, jac.data(), m, (uint8_t*)out);
   return H2_OK;
 }
 

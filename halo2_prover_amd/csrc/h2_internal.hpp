@@ -38,6 +38,8 @@ struct DevCtx {
   int device = -1;
   hipStream_t stream = nullptr;   // the library's own (blocking) stream on this device
   Arena msm_ws, ntt_ws, stage, div_ws;
+  hipEvent_t tail_event = nullptr;   // recorded behind the accumulate kernel of the latest MSM (h2_stream_wait_msm_tail)
+  bool tail_recorded = false, tail_wanted = false;   // the event costs ~5 us per MSM: recorded once somebody asked
   std::vector<TwiddleEntry> twiddles;
   uint64_t stamp = 0;
   // kernel timing for the roofline (h2_profile_*): event pairs around the bucket-accumulate kernel

@@ -61,6 +61,7 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
   // save additions in the accumulate kernel (W = ceil(256 / c)) but every bucket costs ~16 point operations in the
   // tail, so the best width is log2 n - 3 up to 2^16 and log2 n - 4 above
   int c = (int)lg - (lg <= 16 ? 3 : 4);
+  if (const char* ov = getenv("H2_TUNE_C")) c = atoi(ov);   // tuning experiments only (tools/), never set in product runs
   if (c < 6) c = 6;
   if (c > (int)MSM_MAX_C) c = (int)MSM_MAX_C;
   MsmGeom g{};
@@ -715,7 +716,7 @@ inline hipError_t msm_kernel_setup() {
 template <class CV>
 inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_scalars, size_t n, size_t col_stride,
                              size_t m, const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
-                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, hipEvent_t ev_tail = nullptr) {
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
   uint32_t* tile_base = (uint32_t*)(ws_base + ws.off_tile_base);
@@ -760,6 +761,7 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
   hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
                      sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+  if (ev_tail) (void)hipEventRecord(ev_tail, stream);   // from here on only small-grid kernels: other streams may fill the chip
   hipLaunchKernelGGL(msm_hot_reduce_kernel<CV>, dim3(1024), dim3(64), 0, stream, offsets, ws.T, hot_slot, hot_tasks,
                      misc, ws.max_tasks, head, tail, hot_part);
   const size_t fix_threads = ws.K << ws.log_g;

@@ -105,6 +105,13 @@ int h2_msm_batch(h2_curve_t curve, uint64_t bases_handle, const uint64_t* const*
  * (a hipStream_t, NULL = the library's stream); returns without synchronising. */
 int h2_msm_device(h2_curve_t curve, uint64_t bases_handle, const void* d_scalars, size_t n, size_t m,
                   void* d_out_jac, void* stream);
+/* Make `stream` wait until the bucket-accumulate kernel of the most recently enqueued MSM (on any stream) has
+ * finished.  What follows it in an MSM -- the per-bucket fix-up, the bucket weights, the tree sums -- are chains of
+ * dependent point operations on about one wave per SIMD: work queued on another stream behind this wait (the
+ * Lagrange -> coefficient -> extended transforms of columns whose commitment is being computed) runs beside them
+ * instead of beside the chip-filling accumulate kernel.  The first call only switches the marking on (no MSM has
+ * recorded its point yet, so nothing is waited for); bench.py's warm-up steps absorb that. */
+int h2_stream_wait_msm_tail(void* stream);
 /* The same over a contiguous RANGE of the registered bases: result_j = sum_{i<n} scalars_j[i] * bases[first_base + i],
  * columns col_stride elements apart (col_stride >= n).  This is one rank's share of an MSM split by point range over
  * several GPUs (BASELINE config 4): every rank passes its slice of every column, the
