@@ -230,3 +230,35 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["sharded_equals_unsharded"] is True and d["scaling"] == "strong"
+
+
+def test_transforms_queued_behind_an_msm_tail_give_the_same_results(h2):
+    """h2_stream_wait_msm_tail: NTTs on a second stream start when the MSM's accumulate kernel has finished and run
+    beside its tail kernels; bytes as on one stream"""
+    import torch
+    curve, n, m, lg = "bn254", 1 << 14, 3, 16
+    cid = O.CURVE_IDS[curve]
+    b = O.synth_bases(cid, SEED | 0xCB5, n).reshape(n, 8)
+    bases = h2.Bases(curve, b)
+    L = h2.load()
+    try:
+        cols = np.stack([O.synth_scalars(1, SEED | (0xC00 + j), n).reshape(n, 4) for j in range(m)])
+        d = torch.from_numpy(cols.view(np.int64)).cuda()
+        big = O.synth_scalars(1, SEED | 0xC80, 2 << lg).reshape(2, 1 << lg, 4)
+        dbig = torch.from_numpy(big.view(np.int64)).cuda()
+        w = _omega(curve, lg)
+        out = torch.zeros((2, m, 12), dtype=torch.int64, device="cuda")
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for rnd in range(2):                       # the first wait only switches the marking on
+            bases.msm_device(d.data_ptr(), n, m, out[rnd].data_ptr(), sa.cuda_stream)
+            assert L.h2_stream_wait_msm_tail(sb.cuda_stream) == 0
+            h2.ntt_device(dbig[rnd].data_ptr(), 1, w, lg, curve, sb.cuda_stream)
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        for rnd in range(2):
+            for j in range(m):
+                assert np.array_equal(O.to_affine(cid, res[rnd, j]), O.to_affine(cid, O.best_multiexp(cid, cols[j], b, threads=4)))
+            assert np.array_equal(dbig[rnd].cpu().numpy().view(np.uint64), O.best_fft(1, big[rnd], w, lg, threads=8).reshape(-1, 4))
+    finally:
+        bases.release()
