@@ -8,8 +8,9 @@ One "step" = one pass of the hot path over the MSM/NTT calls of ONE Poseidon k=1
 section 8(a)/App. A.4), with dense synthetic columns already resident in HBM:
 
     MSM  n = 2^16 : 4 advice + 2 permutation (over g_lagrange), 1 random-poly + 5 h pieces + 4 GWC
-                    quotients (over g) = 16 MSMs, issued phase by phase (m = 4, 2, 1, 5, 4) as
-                    Fiat-Shamir orders them
+                    quotients (over g) = 16 MSMs, issued as Fiat-Shamir orders them: m = 4, 2 + 1 (the random
+                    polynomial comes from the RNG, not the transcript: it shares the permutation products'
+                    launch, with its own bases), 5, 4
     NTT           : 7 x iNTT(2^16), 7 x NTT(2^19), 1 x iNTT(2^19)   (extended domain, e = 3)
 
 value = field-ops/s with the reference-parameter yardstick of SURVEY.md section 8(d):
@@ -246,7 +247,10 @@ def main():
     g_lagrange, g = make_srs(n, 0x1234567), make_srs(n, 0x7654321)
     plan = g.plan()
 
-    phases = [(g_lagrange, 4), (g_lagrange, 2), (g, 1), (g, 5), (g, 4)] if args.workload == "poseidon" else \
+    # the commit phases of one proof as the transcript orders them.  The vanishing argument's random polynomial is
+    # drawn from the RNG, not from the transcript, so its commitment (over g) shares the launch of the permutation
+    # products (over g_lagrange): 16 MSMs in 4 launch sequences, m = 4, 2 + 1, 5, 4
+    phases = [(g_lagrange, 4), ([g_lagrange, g_lagrange, g], 3), (g, 5), (g, 4)] if args.workload == "poseidon" else \
         [(g, args.msm_cols)] if args.workload == "msm" else []
     n_msm = sum(m for _, m in phases)
     cols_np = splitmix_columns(seed | 1, max(n_msm, 1) * n, p)
@@ -258,8 +262,8 @@ def main():
     if args.workload == "poseidon":
         ntts = [("advice_i", k, 5, True, "beside tail 0"), ("advice_e_a", k + ext, 2, False, "beside tail 0"),
                 ("advice_e_b", k + ext, 3, False, "beside tail 1"),
-                ("z_i", k, 2, True, "beside tail 2"), ("z_e", k + ext, 2, False, "beside tail 2"),
-                ("h_i", k + ext, 1, True, "main stream, before phase 3")]
+                ("z_i", k, 2, True, "beside tail 1"), ("z_e", k + ext, 2, False, "beside tail 1"),
+                ("h_i", k + ext, 1, True, "main stream, before the quotient's commitment")]
     elif args.workload == "ntt":
         ntts = [("cols", k, args.ntt_cols, False, "main")]
     else:
@@ -305,22 +309,20 @@ def main():
         # that it runs beside that phase's small-grid tail instead of beside its chip-filling kernel
         ev_start.record(work_stream)
         side_stream.wait_event(ev_start)
-        off = run_phase(0, 0)
+        off = run_phase(0, 0)                   # advice
         L.h2_stream_wait_msm_tail(side)
         run_ntt("advice_i", side)
         run_ntt("advice_e_a", side)
-        off = run_phase(1, off)                 # the permutation products exist once beta, gamma do: after phase 0
+        off = run_phase(1, off)                 # permutation products (exist once beta, gamma do) + random polynomial
         L.h2_stream_wait_msm_tail(side)
         run_ntt("advice_e_b", side)
-        off = run_phase(2, off)
-        L.h2_stream_wait_msm_tail(side)
         run_ntt("z_i", side)
         run_ntt("z_e", side)
         ev_side_done.record(side_stream)
-        work_stream.wait_event(ev_side_done)    # y is squeezed after phase 2; the quotient needs every extended column
+        work_stream.wait_event(ev_side_done)    # y is squeezed next; the quotient needs every extended column
         run_ntt("h_i", stream)
-        off = run_phase(3, off)
-        run_phase(4, off)
+        off = run_phase(2, off)                 # quotient pieces
+        run_phase(3, off)                       # opening witnesses
 
     for _ in range(args.warmup):
         step()
@@ -460,7 +462,7 @@ def main():
         proof_gen = proof_generation(k, world)
 
     if rank == 0:
-        workload = {"poseidon": "poseidon_k%d_proof_shape: 16 MSM(2^%d) in phases m=4,2,1,5,4 + 7 iNTT(2^%d) + "
+        workload = {"poseidon": "poseidon_k%d_proof_shape: 16 MSM(2^%d) in launches m=4,2+1,5,4 + 7 iNTT(2^%d) + "
                                 "7 NTT(2^%d) + 1 iNTT(2^%d)" % (k, k, k, k + ext, k + ext),
                     "msm": "msm(2^%d) x %d columns" % (k, args.msm_cols), "ntt": "ntt(2^%d) x %d columns" % (k, args.ntt_cols)}[args.workload]
         if world == 1:

@@ -148,6 +148,16 @@ class Bases:
         _lib.check(st, "h2_points_sum_device")
 
 
+def msm_device_multi(bases_list, d_scalars, first_base, n, col_stride, d_out_jac, stream=0):
+    """m = len(bases_list) columns in ONE launch sequence, column j against bases_list[j] (same length and curve):
+    commitments that do not wait for each other although they use different SRS vectors"""
+    m = len(bases_list)
+    handles = (ctypes.c_uint64 * m)(*[b.handle for b in bases_list])
+    st = _lib.load().h2_msm_device_multi(bases_list[0].curve, handles, ctypes.c_void_p(d_scalars), first_base, n, col_stride,
+                                         m, ctypes.c_void_p(d_out_jac), ctypes.c_void_p(stream))
+    _lib.check(st, "h2_msm_device_multi")
+
+
 def init_devices(device_ids):
     """One process, several GPUs (h2_init_devices): host-pointer batches are then sharded over the devices."""
     global _initialised

@@ -192,9 +192,19 @@ static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
 }
 
 int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_scalars, size_t first_base, size_t n,
-                   size_t col_stride, size_t m, void* d_out, bool affine_out, hipStream_t stream) {
+                   size_t col_stride, size_t m, void* d_out, bool affine_out, hipStream_t stream,
+                   const BasesEntry* const* per_column) {
   const size_t group = msm_cols_per_launch(be, n);
   if (group == 0) return H2_EINVAL;
+  // columns with their own bases: one launch only (they must share the registered length, hence the geometry)
+  const void* col_tables[MSM_MAX_MULTI];
+  if (per_column) {
+    if (m > MSM_MAX_MULTI || m > group) return H2_EINVAL;
+    for (size_t j = 0; j < m; j++) {
+      if (per_column[j]->n != be.n || per_column[j]->curve != be.curve) return H2_EINVAL;
+      col_tables[j] = (const char*)per_column[j]->table[ctx_index(&c)] + first_base * 64;
+    }
+  }
   const size_t out_sz = affine_out ? 64 : 96;
   const CurveOps* ops = ops_of(curve);
   // the table rows of bases first_base ...: entries are w * n_bases + i relative to this pointer
@@ -219,7 +229,8 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
       }
     }
     if (c.tail_wanted && !c.tail_event) H2_TRY(hipEventCreateWithFlags(&c.tail_event, hipEventDisableTiming));
-    hipError_t e = ops->msm_launch(table, (uint32_t)be.n, (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
+    hipError_t e = ops->msm_launch(table, per_column ? col_tables : nullptr, (uint32_t)be.n,
+                                   (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
                                    mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1, c.tail_wanted ? c.tail_event : nullptr);
     c.tail_recorded = c.tail_wanted;
     if (e != hipSuccess) return dev_fail(e, "msm_launch");
@@ -487,6 +498,25 @@ int h2_msm_device_range(h2_curve_t curve, uint64_t handle, const void* d_scalars
     return H2_OK;
   }
   return msm_device_run(*k.c, (int)curve, *be, d_scalars, first_base, n, col_stride, m, d_out_jac, false, k.stream);
+}
+
+int h2_msm_device_multi(h2_curve_t curve, const uint64_t* handles, const void* d_scalars, size_t first_base, size_t n,
+                        size_t col_stride, size_t m, void* d_out_jac, void* stream_) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!handles || m == 0 || m > MSM_MAX_MULTI) return H2_EINVAL;
+  const BasesEntry* bes[MSM_MAX_MULTI];
+  for (size_t j = 0; j < m; j++) {
+    int rc = msm_common_checks((int)curve, handles[j], first_base, n, m, &bes[j]);
+    if (rc != H2_OK) return rc;
+  }
+  if (!d_out_jac || (n && !d_scalars) || (m > 1 && col_stride < n)) return H2_EINVAL;
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
+  if (n == 0) {
+    H2_TRY(hipMemsetAsync(d_out_jac, 0, m * 96, k.stream));
+    return H2_OK;
+  }
+  return msm_device_run(*k.c, (int)curve, *bes[0], d_scalars, first_base, n, col_stride, m, d_out_jac, false, k.stream, bes);
 }
 
 int h2_msm_device(h2_curve_t curve, uint64_t handle, const void* d_scalars, size_t n, size_t m, void* d_out_jac,

@@ -20,7 +20,7 @@ struct CurveOps {
   hipError_t (*kernel_setup)();
   // MSM
   hipError_t (*table_build)(const void* d_bases, void* d_table, uint32_t n, const MsmGeom& g, hipStream_t s);
-  hipError_t (*msm_launch)(const void* d_table, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
+  hipError_t (*msm_launch)(const void* d_table, const void* const* per_column_tables, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
                            const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s,
                            hipEvent_t ev_start, hipEvent_t ev_stop, hipEvent_t ev_tail);
   hipError_t (*srs_powers)(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s);

@@ -93,8 +93,11 @@ int arena_release(Arena& a, hipStream_t s);
 
 // enqueue m MSMs (columns of n scalars, col_stride elements apart, bases first_base ... first_base + n - 1 of the
 // registered vector) -> m Jacobian (96 B) or affine (64 B) points at d_out; all on `stream`
+// `per_column` (optional, m <= MSM_MAX_MULTI entries of the same length as `be`): column j commits against
+// per_column[j] instead of `be` -- the columns of one launch may use different bases
 int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_scalars, size_t first_base, size_t n,
-                   size_t col_stride, size_t m, void* d_out, bool affine_out, hipStream_t stream);
+                   size_t col_stride, size_t m, void* d_out, bool affine_out, hipStream_t stream,
+                   const BasesEntry* const* per_column = nullptr);
 int ntt_enqueue(DevCtx& c, int curve, void* d_a, size_t m, const uint64_t omega[4], uint32_t log_n, hipStream_t stream,
                 const uint64_t* scale = nullptr);
 int msm_common_checks(int curve, uint64_t handle, size_t first, size_t n, size_t m, const BasesEntry** be);

@@ -297,9 +297,13 @@ __device__ __forceinline__ Affine29<CV> msm_fetch(const U128* __restrict__ table
 
 // Chunk t covers sorted entries [t*T, min((t+1)*T, E)), E = offsets[K] read on the device.  A run (maximal stretch of one key inside the chunk) that holds the key's
 // whole list goes to bucket_sum[key]; a cut-off first run goes to head[t], a cut-off last run to tail[t].
+// `col_tables` (optional): one table per column -- columns of ONE launch may commit against different bases of the same
+// length (a proof's permutation products over g_lagrange and its random polynomial over g share a launch); the
+// column of a key is key >> log_b.  Null: every column uses `table`.
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ sorted_ref,
+msm_chunk_kernel(const U128* __restrict__ table, const U128* const* __restrict__ col_tables, uint32_t log_b,
+                 const uint32_t* __restrict__ sorted_ref,
                  const uint32_t* __restrict__ chunk_first, const uint32_t* __restrict__ offsets, size_t K, uint32_t T,
                  uint32_t* __restrict__ bucket_sum, uint32_t* __restrict__ head, uint32_t* __restrict__ tail) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,6 +313,7 @@ msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ so
   const uint32_t lo = (uint32_t)lo64, hi = (uint32_t)min((uint64_t)E, lo64 + T);
   uint32_t key = chunk_first[t];
   uint32_t next = offsets[key + 1];          // first entry of the following list
+  if (col_tables) table = col_tables[key >> log_b];
   bool first = true;
   Xyzz29<CV> a = Xyzz29<CV>::identity();
   U128 quad = U128{0, 0, 0, 0};
@@ -328,6 +333,7 @@ msm_chunk_kernel(const U128* __restrict__ table, const uint32_t* __restrict__ so
         key++;
         next = offsets[key + 1];
       } while (e >= next);
+      if (col_tables) table = col_tables[key >> log_b];
     }
     a = xyzz29_add_affine(a, msm_fetch<CV>(table, ref));
   }
@@ -515,6 +521,14 @@ msm_tree_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
     a = xyzz29_add_quad(a, xyzz29_load<CV>(in + XYZZ29_WORDS * ((size_t)col * count + idx)));
   for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz29_add_quad(a, xyzz_shfl_down(a, d));
   if (threadIdx.x == 0) xyzz29_store<CV>(out + XYZZ29_WORDS * ((size_t)col * out_per_col + blockIdx.x), a);
+}
+
+constexpr uint32_t MSM_MAX_MULTI = 16;    // columns of a launch that may each bring their own bases
+struct MsmTableList {
+  const U128* t[MSM_MAX_MULTI];
+};
+static __global__ void msm_store_tables_kernel(MsmTableList L, const U128** dst, uint32_t m) {
+  if (threadIdx.x < m) dst[threadIdx.x] = L.t[threadIdx.x];
 }
 
 // ---- finish: XYZZ -> Jacobian (m points) ---------------------------------------------------------
@@ -714,7 +728,8 @@ inline hipError_t msm_kernel_setup() {
 // Result: m XYZZ points at ws_base + off_tree2.  ev_start / ev_stop (optional) bracket the
 // accumulate (chunk) kernel for the roofline measurement.
 template <class CV>
-inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_scalars, size_t n, size_t col_stride,
+inline hipError_t msm_launch(const U128* table, const U128* const* per_column /* host array of m tables, or null */,
+                             uint32_t n_bases, const U128* d_scalars, size_t n, size_t col_stride,
                              size_t m, const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, hipEvent_t ev_tail = nullptr) {
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
@@ -757,9 +772,19 @@ inline hipError_t msm_launch(const U128* table, uint32_t n_bases, const U128* d_
                      tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
+  const U128** d_tables = nullptr;
+  uint32_t log_b = 0;
+  if (per_column) {
+    if (m > MSM_MAX_MULTI) return hipErrorInvalidValue;
+    MsmTableList L{};
+    for (size_t j = 0; j < m; j++) L.t[j] = per_column[j];
+    d_tables = (const U128**)(misc + 16);                          // 128 bytes of the 256-byte misc block
+    hipLaunchKernelGGL(msm_store_tables_kernel, dim3(1), dim3(64), 0, stream, L, d_tables, (uint32_t)m);
+    while ((1u << log_b) < g.B) log_b++;
+  }
   if (ev_start) (void)hipEventRecord(ev_start, stream);
   hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
-                     sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
+                     (const U128* const*)d_tables, log_b, sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   if (ev_tail) (void)hipEventRecord(ev_tail, stream);   // from here on only small-grid kernels: other streams may fill the chip
   hipLaunchKernelGGL(msm_hot_reduce_kernel<CV>, dim3(1024), dim3(64), 0, stream, offsets, ws.T, hot_slot, hot_tasks,

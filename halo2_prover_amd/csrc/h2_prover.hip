@@ -550,11 +550,21 @@ Fr fr_delta() {   // DELTA = 7^(2^28): generator of the coset structure of the p
 }
 
 // m columns of n scalars -> m commitments (affine, canonical coordinates)
-std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange) {
+// `split` < m: columns [0, split) commit against g_lagrange and [split, m) against g IN THE SAME LAUNCH (commitments
+// that do not wait for each other: the permutation products and the RNG-drawn random polynomial)
+std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange, size_t split = ~(size_t)0) {
   auto it = g_h2.bases.find(lagrange ? P.h_gl : P.h_g);
   if (it == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
   void* out = d.alloc(m * 96);
-  st_ok(msm_device_run(*d.c, H2_BN254, it->second, cols, 0, n, n, m, out, false, d.s), "msm_device_run");
+  if (split < m) {
+    auto ig = g_h2.bases.find(P.h_g), il = g_h2.bases.find(P.h_gl);
+    if (ig == g_h2.bases.end() || il == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
+    std::vector<const BasesEntry*> per(m);
+    for (size_t j = 0; j < m; j++) per[j] = j < split ? &il->second : &ig->second;
+    st_ok(msm_device_run(*d.c, H2_BN254, il->second, cols, 0, n, n, m, out, false, d.s, per.data()), "msm_device_run");
+  } else {
+    st_ok(msm_device_run(*d.c, H2_BN254, it->second, cols, 0, n, n, m, out, false, d.s), "msm_device_run");
+  }
   std::vector<uint8_t> raw(m * 96);
   hip_ok(hipMemcpyAsync(raw.data(), out, raw.size(), hipMemcpyDeviceToHost, d.s), "hipMemcpyAsync(D2H)");
   d.sync();
@@ -787,8 +797,10 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
   if (public_input.size() > n - (uint32_t)(bf + 1)) fail(H2_EINVAL, "instance too long");
   if (!ni && !public_input.empty()) fail(H2_EINVAL, "circuit has no instance column");
   // Lagrange columns of this proof: advice | instance | z
-  Col lag = d.col((na + ni + nz) * (size_t)n);
+  // ... | random polynomial (coefficient form; it sits behind the z columns so that both share one MSM launch)
+  Col lag = d.col((na + ni + nz + 1) * (size_t)n);
   Col advice_values = lag, instance_values = lag + 2 * na * (size_t)n, z_values = lag + 2 * (na + ni) * (size_t)n;
+  Col random_poly = lag + 2 * (na + ni + nz) * (size_t)n;
   if (ni) {
     std::vector<SparseCol> inst(1);
     for (size_t i = 0; i < public_input.size(); i++) inst[0][(uint32_t)i] = public_input[i];
@@ -865,12 +877,9 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
     d.release(ratio);
   }
   trace.mark("grand products built");
-  if (nz)
-    for (auto& pt : commit(d, P, z_values, n, nz, true)) tr.write_point(pt);
-  trace.mark("grand products committed");
-
-  // the vanishing argument's random polynomial: one ChaCha20 seed, n sequential draws
-  Col random_poly = d.col(n);
+  // the vanishing argument's random polynomial: one ChaCha20 seed, n sequential draws.  It comes from the RNG, not
+  // from the transcript, so its commitment (over g) is computed in the launch of the permutation products' (over
+  // g_lagrange); the transcript still receives the points in the reference's order
   {
     uint8_t seed[32];
     rng.fill(seed, 32);
@@ -879,8 +888,8 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
     hip_ok(d.ops->chacha20_scalars(random_poly, n, 0, key, d.s), "chacha20_scalars");
     (void)rng.fr_random();
   }
-  tr.write_point(commit(d, P, random_poly, n, 1, false)[0]);
-  trace.mark("random poly committed");
+  for (auto& pt : commit(d, P, z_values, n, nz + 1, true, nz)) tr.write_point(pt);
+  trace.mark("grand products + random poly committed");
 
   // coefficient forms, then the extended coset
   Col polys = d.col((na + ni + nz) * (size_t)n);

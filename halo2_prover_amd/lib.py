@@ -46,6 +46,7 @@ SYMBOLS = {
     "h2_msm_device_range": (_I, [_I, _U64, _P, _Z, _Z, _Z, _Z, _P, _P]),
     "h2_points_sum_device": (_I, [_I, _P, _Z, _Z, _P, _P]),
     "h2_stream_wait_msm_tail": (_I, [_P]),
+    "h2_msm_device_multi": (_I, [_I, _P, _P, _Z, _Z, _Z, _Z, _P, _P]),
     "h2_ntt": (_I, [_I, _P, _P, _U32]),
     "h2_ntt_batch": (_I, [_I, _P, _Z, _P, _U32]),
     "h2_ntt_device": (_I, [_I, _P, _Z, _P, _U32, _P]),

@@ -91,10 +91,20 @@ def all_gather_rows(local, group=None):
     return recv.view(world, rows, w).to(local.device)
 
 
+def _run(bases, d_cols, first, n, stride, cols, d_out, stream):
+    """`cols` = the column indices (of the phase) in this launch; `bases` one Bases for all columns or a list per column"""
+    if isinstance(bases, (list, tuple)):
+        from .api import msm_device_multi
+        msm_device_multi([bases[j] for j in cols], d_cols, first, n, stride, d_out, stream)
+    else:
+        bases.msm_device_range(d_cols, first, n, stride, len(cols), d_out, stream)
+
+
 def msm_phase_device(bases, d_cols, n, m, stream=0, group=None, mode=None, device=None):
     """The m commitments of one proof phase on the GPUs of `group`: d_cols is a device pointer to m columns of n
     scalars (stride n), identical on every rank; returns an (m, 12) int64 CUDA tensor of Jacobian points, the same
-    group elements on every rank, in column order.
+    group elements on every rank, in column order.  `bases`: one Bases object, or a list of m (column j commits against
+    bases[j]: commitments over different SRS vectors that do not wait for each other share the launch).
 
     "columns": rank r runs columns r, r + world, ... whole, one all-gather of the 96-byte results.
     "range":   rank r runs bases / rows [n r / world, n (r+1) / world) of every column in one batched launch
@@ -112,23 +122,23 @@ def msm_phase_device(bases, d_cols, n, m, stream=0, group=None, mode=None, devic
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     if mode == "single" or not have_group:
         out = torch.empty((m, 12), dtype=torch.int64, device=dev)
-        bases.msm_device_range(d_cols, 0, n, n, m, out.data_ptr(), stream)
+        _run(bases, d_cols, 0, n, n, list(range(m)), out.data_ptr(), stream)
         return out
     if mode == "columns":
         mine = len(range(rank, m, world))
         slots = (m + world - 1) // world
         local = torch.zeros((slots, 12), dtype=torch.int64, device=dev)
         if mine:
-            bases.msm_device_range(d_cols + rank * n * 32, 0, n, world * n, mine, local.data_ptr(), stream)
+            _run(bases, d_cols + rank * n * 32, 0, n, world * n, list(range(rank, m, world)), local.data_ptr(), stream)
         allr = all_gather_rows(local, group)                    # (world, slots, 12): column r + i * world at [r][i]
         return allr.transpose(0, 1).reshape(slots * world, 12)[:m].contiguous()
     lo, hi = split_msm_by_range(n, rank, world)
     local = torch.zeros((m, 12), dtype=torch.int64, device=dev)
     if hi > lo:
-        bases.msm_device_range(d_cols + lo * 32, lo, hi - lo, n, m, local.data_ptr(), stream)
+        _run(bases, d_cols + lo * 32, lo, hi - lo, n, list(range(m)), local.data_ptr(), stream)
     allr = all_gather_rows(local, group)                        # (world, m, 12)
     out = torch.empty((m, 12), dtype=torch.int64, device=dev)
-    bases.points_sum_device(allr.data_ptr(), world, m, out.data_ptr(), stream)
+    (bases[0] if isinstance(bases, (list, tuple)) else bases).points_sum_device(allr.data_ptr(), world, m, out.data_ptr(), stream)
     return out
 
 

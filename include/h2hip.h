@@ -105,6 +105,12 @@ int h2_msm_batch(h2_curve_t curve, uint64_t bases_handle, const uint64_t* const*
  * (a hipStream_t, NULL = the library's stream); returns without synchronising. */
 int h2_msm_device(h2_curve_t curve, uint64_t bases_handle, const void* d_scalars, size_t n, size_t m,
                   void* d_out_jac, void* stream);
+/* m columns, column j against the bases registered under handles[j] (all of the same length and curve; m <= 16):
+ * ONE launch sequence for commitments that do not wait for each other although they use different SRS vectors --
+ * in create_proof the permutation products (over g_lagrange) and the vanishing argument's random polynomial (over g,
+ * drawn from the RNG, not from the transcript).  first_base / n / col_stride as in h2_msm_device_range.  Every MSM call pays ~0.3 ms of sort + small-grid tail whatever m is. */
+int h2_msm_device_multi(h2_curve_t curve, const uint64_t* bases_handles /* m */, const void* d_scalars,
+                        size_t first_base, size_t n, size_t col_stride, size_t m, void* d_out_jac, void* stream);
 /* Make `stream` wait until the bucket-accumulate kernel of the most recently enqueued MSM (on any stream) has
  * finished.  What follows it in an MSM -- the per-bucket fix-up, the bucket weights, the tree sums -- are chains of
  * dependent point operations on about one wave per SIMD: work queued on another stream behind this wait (the

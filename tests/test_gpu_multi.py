@@ -262,3 +262,39 @@ def test_transforms_queued_behind_an_msm_tail_give_the_same_results(h2):
             assert np.array_equal(dbig[rnd].cpu().numpy().view(np.uint64), O.best_fft(1, big[rnd], w, lg, threads=8).reshape(-1, 4))
     finally:
         bases.release()
+
+
+def test_one_launch_with_different_bases_per_column(h2):
+    """h2_msm_device_multi: column j against its own registered bases (same length), incl. a sub-range"""
+    import torch
+    from halo2_prover_amd import api
+    curve, n, m = "bn254", 3000, 4
+    cid = O.CURVE_IDS[curve]
+    ba = O.synth_bases(cid, SEED | 0xDB5, n).reshape(n, 8)
+    bb = O.synth_bases(cid, SEED | 0xDB6, n).reshape(n, 8)
+    A, B = h2.Bases(curve, ba), h2.Bases(curve, bb)
+    try:
+        cols = np.stack([O.synth_scalars(1, SEED | (0xD00 + j), n).reshape(n, 4) for j in range(m)])
+        d = torch.from_numpy(cols.view(np.int64)).cuda()
+        out = torch.zeros((m, 12), dtype=torch.int64, device="cuda")
+        which = [A, B, B, A]
+        api.msm_device_multi(which, d.data_ptr(), 0, n, n, out.data_ptr())
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        for j in range(m):
+            want = O.best_multiexp(cid, cols[j], ba if which[j] is A else bb)
+            assert np.array_equal(O.to_affine(cid, res[j]), O.to_affine(cid, want)), j
+        lo, cnt = 1234, 1500
+        api.msm_device_multi(which, d.data_ptr() + lo * 32, lo, cnt, n, out.data_ptr())
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        for j in range(m):
+            bs = (ba if which[j] is A else bb)[lo:lo + cnt].copy()
+            assert np.array_equal(O.to_affine(cid, res[j]), O.to_affine(cid, O.best_multiexp(cid, cols[j][lo:lo + cnt].copy(), bs))), j
+        short = h2.Bases(curve, ba[:100])
+        with pytest.raises(h2.H2Error):                    # different registered lengths cannot share a launch
+            api.msm_device_multi([A, short], d.data_ptr(), 0, 100, n, out.data_ptr())
+        short.release()
+    finally:
+        A.release()
+        B.release()
