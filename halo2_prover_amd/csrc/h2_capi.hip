@@ -154,9 +154,21 @@ static int register_device(DevCtx& src, int curve, const void* d_affine, size_t 
   const size_t si = ctx_index(&src);
   {
     DeviceGuard dg(src.device);
-    hipError_t e = ops->table_build(d_affine, be.table[si], (uint32_t)n, g, src.stream);
+    // the points are checked while the table is built: a counter in the (otherwise idle) scan arena
+    int rc = arena_acquire(src.div_ws, (size_t)2 * DIV_MAX_CHUNKS * 32, src.stream);
+    if (rc != H2_OK) return fail(rc);
+    uint32_t* d_bad = (uint32_t*)src.div_ws.p;
+    uint32_t bad = 0;
+    hipError_t e = hipMemsetAsync(d_bad, 0, 4, src.stream);
+    if (e == hipSuccess) e = ops->table_build(d_affine, be.table[si], (uint32_t)n, g, d_bad, src.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, src.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(src.stream);
     if (e != hipSuccess) return fail(dev_fail(e, "msm_table_kernel"));
+    (void)arena_release(src.div_ws, src.stream);
+    if (bad) {
+      g_h2.last_error = "bases: " + std::to_string(bad) + " point(s) not on the curve";
+      return fail(H2_EINVAL);
+    }
     for (size_t i = 0; i < g_h2.ctx.size(); i++) {
       if (i == si) continue;
       e = hipMemcpyPeer(be.table[i], g_h2.ctx[i].device, be.table[si], src.device, be.table_bytes);

@@ -81,13 +81,30 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
 }
 
 // ---- table build: T[w][i] = 2^(off_w) * P_i, affine -----------------------------------------
+// `bad` counts the points that are neither the identity (0, 0) nor on the curve y^2 = x^3 + b (or whose
+// coordinates are not canonical): the reference reads its params with curve checks (SerdeFormat::RawBytes)
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint32_t n, MsmGeom g) {
+msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint32_t n, MsmGeom g, uint32_t* __restrict__ bad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   using B = typename CV::Base;
   Affine<CV> p = affine_load<CV>(bases + 4 * (size_t)i);
+  if (!p.is_identity()) {
+    Fe<B> b;
+#pragma unroll
+    for (int k = 0; k < 8; k++) b.v[k] = CV::B(k);
+    uint32_t rx[8], ry[8];
+    fe_reduce_once<B>(rx, p.x.v, 0);                    // canonical <=> unchanged by the conditional subtraction
+    fe_reduce_once<B>(ry, p.y.v, 0);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ok = ok && rx[k] == p.x.v[k] && ry[k] == p.y.v[k];
+    if (!ok || fe_sqr(p.y) != fe_add(fe_mul(fe_sqr(p.x), p.x), b)) {
+      atomicAdd(bad, 1u);
+      p = Affine<CV>::identity();                       // keep the kernel's arithmetic on valid points
+    }
+  }
   Xyzz<CV> cur = xyzz_from_affine(p);
   for (uint32_t w = 0; w < g.W; w++) {
     Affine<CV> a = (w == 0) ? p : xyzz_to_affine(cur);

@@ -370,8 +370,13 @@ const Params& params_get(const uint8_t* bytes, size_t len) {
   p.k = k;
   p.digest = dg;
   // the reference reads with SerdeFormat::RawBytes (wasm.rs:79-80): raw Montgomery limbs, 64 B per G1 point
-  st_ok(h2_bases_register(H2_BN254, (const uint64_t*)(bytes + 4), n, &p.h_g), "h2_bases_register(g)");
-  st_ok(h2_bases_register(H2_BN254, (const uint64_t*)(bytes + 4 + 64 * n), n, &p.h_gl), "h2_bases_register(g_lagrange)");
+  int rc = h2_bases_register(H2_BN254, (const uint64_t*)(bytes + 4), n, &p.h_g);
+  if (rc == H2_EINVAL) fail(H2_EPROOF, "params: g holds a point that is not on the curve");
+  st_ok(rc, "h2_bases_register(g)");
+  rc = h2_bases_register(H2_BN254, (const uint64_t*)(bytes + 4 + 64 * n), n, &p.h_gl);
+  if (rc != H2_OK) (void)h2_bases_release(p.h_g);
+  if (rc == H2_EINVAL) fail(H2_EPROOF, "params: g_lagrange holds a point that is not on the curve");
+  st_ok(rc, "h2_bases_register(g_lagrange)");
   p.g0 = affine_from_raw(bytes + 4);
   const uint8_t* t = bytes + 4 + 128 * n;
   p.g2 = bn::G2{{fq_from_mont(t), fq_from_mont(t + 32)}, {fq_from_mont(t + 64), fq_from_mont(t + 96)}, false};
@@ -771,7 +776,16 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   trace.mark("program compiled");
   d.sync();
   trace.mark("synchronised");
-  if (trace.on) fprintf(stderr, "[h2 keygen] quotient program: %zu instructions, %u slots, %zu constants\n", X.code.size(), X.nslots, X.consts.size());
+  if (trace.on) {
+    size_t nmul = 0, ncol = 0;
+    for (auto& ins : X.code) {
+      if ((ins.op_dst >> 24) == 2) nmul++;
+      if ((ins.a & (3u << 30)) == pk::X_COL) ncol++;
+      if ((ins.b & (3u << 30)) == pk::X_COL) ncol++;
+    }
+    fprintf(stderr, "[h2 keygen] quotient program: %zu instructions (%zu products), %zu column reads, %u slots, %zu constants\n",
+            X.code.size(), nmul, ncol, X.nslots, X.consts.size());
+  }
   return pkp;
 }
 

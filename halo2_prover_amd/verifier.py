@@ -22,6 +22,7 @@ import numpy as np
 
 from . import pairing as _pairing
 from .api import ParamsKZG, best_multiexp
+from .lib import H2Error
 from .prover import (DELTA, P, Q, R_P, R_Q, R_Q_INV, ArithmeticCircuit, CollatzCircuit, PoseidonCircuit,
                      _horner, _interpolate, generate_keys)
 
@@ -398,6 +399,10 @@ def wasm_verify_proof(params_bytes, proof, s, circuit_index):
         return verify_with_instance(params, generate_keys(params, circuit), proof, [circuit.output()])
     except (ValueError, KeyError, TypeError):
         return False
+    except H2Error as e:
+        if e.status == -1:          # params hold a point that is not on the curve (ParamsKZG::read would fail)
+            return False
+        raise
 
 
 def wasm_simulate_circuit(s, circuit_index):

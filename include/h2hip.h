@@ -82,7 +82,9 @@ int h2_version(void);
  * Registers n affine points and keeps them -- plus the table of their 2^(c*w) multiples that
  * lets every Pippenger window share one bucket set -- resident in HBM.  Replaces the `bases`
  * slice argument of best_multiexp for all later calls (ParamsKZG::commit_lagrange passes
- * g_lagrange, ParamsKZG::commit passes g).  `affine` is a host pointer. */
+ * g_lagrange, ParamsKZG::commit passes g).  `affine` is a host pointer.  Every point must be the
+ * identity (0, 0) or lie on the curve with canonical coordinates (checked on the device while the table is built, as
+ * the reference's ParamsKZG::read checks with SerdeFormat::RawBytes): otherwise H2_EINVAL. */
 int h2_bases_register(h2_curve_t curve, const uint64_t* affine /* n*8 */, size_t n, uint64_t* handle_out);
 /* Same, from a device pointer (the points are copied; the caller keeps ownership). */
 int h2_bases_register_device(h2_curve_t curve, const void* d_affine, size_t n, uint64_t* handle_out);

@@ -261,6 +261,11 @@ def test_malformed_inputs_are_status_codes(h2, lib):
     ok = ctypes.c_int(-1)
     assert lib.h2_verify_proof(p4, len(p4), b"x", 1, b"{", 1, ctypes.byref(ok)) == -6
     assert lib.h2_setup(0, None, None, out, 4096, ctypes.byref(n)) == -1
+    corrupt = bytearray(p4)
+    corrupt[4 + 64 * 3 + 7] ^= 0x10                                     # g[3] is no longer on the curve
+    assert lib.h2_generate_proof(bytes(corrupt), len(corrupt), ARITH_INPUT.encode(), 1, None, None, out, 4096, ctypes.byref(n)) == -6
+    from halo2_prover_amd import verifier as V
+    assert V.wasm_verify_proof(bytes(corrupt), golden("proof_arithmetic_k4.bin"), ARITH_INPUT, 1) is False
 
 
 @pytest.mark.gpu

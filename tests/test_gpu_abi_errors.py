@@ -65,3 +65,24 @@ def test_python_mirror_raises_where_the_reference_panics(h2):
         h2.ParamsKZG.read(b"\\x04\\x00\\x00\\x00" + bytes(10))     # truncated params file
     with pytest.raises(KeyError):
         h2.best_multiexp(s, b, "bls12-381")
+
+
+def test_bases_off_the_curve_are_rejected(h2):
+    """h2_bases_register checks every point on the device while it builds the table (the reference reads params with
+    SerdeFormat::RawBytes, i.e. with curve checks)"""
+    import oracle_lib as O
+    n = 300
+    b = O.synth_bases(0, 0x48324D53000000E5, n).reshape(n, 8).copy()
+    h2.Bases("bn254", b).release()
+    bad = b.copy()
+    bad[137, 0] ^= np.uint64(1)                                  # x of one point off by one
+    with pytest.raises(h2.H2Error) as err:
+        h2.Bases("bn254", bad)
+    assert err.value.status == -1
+    ident = b.copy()
+    ident[5] = 0                                                 # the identity (0, 0) is a valid base
+    h2.Bases("bn254", ident).release()
+    noncanon = b.copy()
+    noncanon[9, 0:4] = np.array([0xFFFFFFFFFFFFFFFF] * 4, dtype=np.uint64)   # x >= p
+    with pytest.raises(h2.H2Error):
+        h2.Bases("bn254", noncanon)
