@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sub-records: modmul ceiling, 2^20 headline MSM (config 4), config 5")
     ap.add_argument("--config5-k", type=int, default=24, help="rows of the config-5 sub-record (N > 1 only)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="rehearsal: take the N > 1 code paths (range split, all-gather, partial-sum addition, config 5) even "
+                         "with one rank -- run under torch.distributed.run with one rank to exercise RCCL on a one-GPU box")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
@@ -274,6 +277,7 @@ def main():
         if mine:
             allc = splitmix_columns(seed | (2 + j), m << lg, p).reshape(m, 1 << lg, 4)
             ntt_bufs[name] = (to_dev(np.ascontiguousarray(allc[mine]).reshape(-1, 4)), lg, len(mine), omega(lg, inv))
+    multi = world > 1 or (args.force_collectives and use_dist)
     results = [None] * len(phases)
     side_stream = torch.cuda.Stream(device=dev, priority=0)
     side = side_stream.cuda_stream
@@ -282,10 +286,12 @@ def main():
     def run_phase(i, off, mode=None):
         bases, m = phases[i]
         results[i] = sharded.msm_phase_device(bases, msm_cols.data_ptr() + off * n * 32, n, m, stream,
-                                              mode=mode if world > 1 else "single")
+                                              mode=mode if multi else "single")
         return off + m
 
     def msm_phase(mode=None):
+        if mode is None and multi and world == 1:
+            mode = "range"
         off = 0
         for i in range(len(phases)):
             off = run_phase(i, off, mode)
@@ -340,7 +346,7 @@ def main():
     prof = h2lib.Profile()
     h2lib.check(L.h2_profile_read(ctypes.byref(prof)), "h2_profile_read")
     L.h2_profile_enable(0)
-    if use_dist and world > 1:
+    if use_dist and multi:
         t = torch.tensor([dt], dtype=torch.float64)
         if backend == "nccl":
             t = t.to(dev)
@@ -349,7 +355,7 @@ def main():
 
     # sharded == whole: every rank recomputes the phases alone on its own GPU and compares group elements
     sharded_ok = None
-    if world > 1 and phases:
+    if multi and phases:
         q = BASE_FIELD[args.curve]
         got = [jac_to_affine_ints(r.cpu().numpy().view(np.uint64), q) for r in results]
         msm_phase(mode="single")
@@ -452,8 +458,8 @@ def main():
         del msm_cols
         ntt_bufs.clear()
         torch.cuda.empty_cache()
-        extras["headline_msm_2e20"] = headline_msm(args, 20, make_srs, world, rank, dev, stream, barrier, modmul, p)
-        if world > 1:
+        extras["headline_msm_2e20"] = headline_msm(args, 20, make_srs, world, rank, dev, stream, barrier, modmul, p, multi)
+        if multi:
             extras["config5"] = config5(args, make_srs, world, rank, dev, stream, barrier, p, gen, two_adicity, R)
 
     proof_gen = None
@@ -507,7 +513,7 @@ def _device_scalars(L, cid, count, seed_byte, dev, stream):
     return t
 
 
-def headline_msm(args, lg, make_srs, world, rank, dev, stream, barrier, modmul, p):
+def headline_msm(args, lg, make_srs, world, rank, dev, stream, barrier, modmul, p, multi=False):
     """BASELINE config 4 / the north star's named target: ONE MSM of 2^20 terms.  N = 1: one launch sequence on one
     GPU.  N > 1: contiguous point-range split, rank r runs bases [n r / N, n (r+1) / N) against the replicated table,
     the N partial sums are all-gathered (96 B each) and added on the device.  Timed with the barrier + max-over-ranks
@@ -526,7 +532,8 @@ def headline_msm(args, lg, make_srs, world, rank, dev, stream, barrier, modmul, 
     def run(mode):
         return sharded.msm_phase_device(bases, col.data_ptr(), n, 1, stream, mode=mode)
 
-    mode = "range" if world > 1 else "single"
+    multi = multi or world > 1
+    mode = "range" if multi else "single"
     run(mode)
     barrier()
     t0 = time.perf_counter()
@@ -534,14 +541,14 @@ def headline_msm(args, lg, make_srs, world, rank, dev, stream, barrier, modmul, 
         out = run(mode)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64)
         if dist.get_backend() == "nccl":
             t = t.to(dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ok = None
-    if world > 1:
+    if multi:
         q = BASE_FIELD[args.curve]
         whole = run("single")
         torch.cuda.synchronize()
