@@ -285,6 +285,31 @@ struct Dev {
     hip_ok(ops->poly_prefix_product(a, n, out, c->div_ws.p, s), "poly_prefix_product");
     st_ok(arena_release(c->div_ws, s), "arena");
   }
+  // mode 0: q_j = (a_j - a_j(z_j)) / (X - z_j); mode 1: out_j[i] = prod_{t < i} a_j[t] -- all jobs in one launch sequence
+  void scan_batch(int mode, uint32_t n, const std::vector<Col>& in, const std::vector<Col>& out, const std::vector<Fr>& z) {
+    for (size_t j0 = 0; j0 < in.size(); j0 += pk::SCAN_MAX_JOBS) {
+      const size_t cnt = std::min<size_t>(pk::SCAN_MAX_JOBS, in.size() - j0);
+      uint32_t L = (n + pk::SCAN_CHUNKS - 1) / pk::SCAN_CHUNKS;
+      if (L < 16) L = 16;
+      const uint32_t C = (n + L - 1) / L;
+      pk::ScanBatch B{};
+      for (size_t j = 0; j < cnt; j++) {
+        B.a[j] = in[j0 + j];
+        B.out[j] = out[j0 + j];
+        if (mode == 0) {
+          B.z[j] = z[j0 + j].v;
+          B.w[j] = z[j0 + j].pow_u64(L).v;
+        }
+      }
+      Col ws = col((size_t)2 * cnt * pk::SCAN_CHUNKS);
+      Col H = ws, G = ws + 2 * cnt * (size_t)pk::SCAN_CHUNKS;
+      hipLaunchKernelGGL(pk::scan_chunk_kernel, dim3((C + 63) / 64, (unsigned)cnt), dim3(64), 0, s, B, mode, n, L, C, H);
+      hipLaunchKernelGGL(pk::scan_block_kernel, dim3((unsigned)cnt), dim3(pk::SCAN_CHUNKS), 0, s, B, mode, C, H, G);
+      hipLaunchKernelGGL(pk::scan_apply_kernel, dim3((C + 63) / 64, (unsigned)cnt), dim3(64), 0, s, B, mode, n, L, C, G);
+      hip_ok(hipGetLastError(), "scan_batch kernels");
+      release(ws);
+    }
+  }
   // values of `jobs` = (polynomial, point) pairs, all polynomials of n coefficients
   std::vector<Fr> evaluate(const std::vector<std::pair<Col, Fr>>& jobs, uint32_t n) {
     if (jobs.empty()) return {};
@@ -869,7 +894,14 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
                          K.omega_col, ratio + 2 * s0 * (size_t)n, n);
       hip_ok(hipGetLastError(), "perm_ratio_kernel");
     }
-    for (size_t si = 0; si < nz; si++) d.prefix_product(ratio + 2 * si * (size_t)n, n, z_values + 2 * si * (size_t)n);
+    {
+      std::vector<Col> in, out;
+      for (size_t si = 0; si < nz; si++) {
+        in.push_back(ratio + 2 * si * (size_t)n);
+        out.push_back(z_values + 2 * si * (size_t)n);
+      }
+      d.scan_batch(1, n, in, out, {});
+    }
     // the products over the usable rows (row n - bf - 1 of every prefix column): one gather, one copy back
     Col tails_d = d.col(nz);
     for (size_t si = 0; si < nz; si++) d.copy(tails_d + 2 * si, z_values + 2 * (si * (size_t)n + (n - bf - 1)), 32);
@@ -1023,17 +1055,22 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
   for (auto& q : queries)
     if (std::find(points.begin(), points.end(), q.point) == points.end()) points.push_back(q.point);
   Col witnesses = d.col(points.size() * (size_t)n);
-  Col acc = d.col(n);
-  for (size_t pi = 0; pi < points.size(); pi++) {
-    std::vector<std::pair<Col, Fr>> t;
-    Fr vp = Fr::one();
-    for (auto& q : queries)
-      if (q.point == points[pi]) {
-        t.push_back({q.poly, vp});
-        vp *= v;
-      }
-    d.lincomb(acc, n, t);
-    d.divide_linear(acc, n, points[pi], witnesses + 2 * pi * (size_t)n);
+  Col accs = d.col(points.size() * (size_t)n);
+  {
+    std::vector<Col> in, out;
+    for (size_t pi = 0; pi < points.size(); pi++) {
+      std::vector<std::pair<Col, Fr>> t;
+      Fr vp = Fr::one();
+      for (auto& q : queries)
+        if (q.point == points[pi]) {
+          t.push_back({q.poly, vp});
+          vp *= v;
+        }
+      d.lincomb(accs + 2 * pi * (size_t)n, n, t);
+      in.push_back(accs + 2 * pi * (size_t)n);
+      out.push_back(witnesses + 2 * pi * (size_t)n);
+    }
+    d.scan_batch(0, n, in, out, points);          // the four synthetic divisions side by side
   }
   for (auto& pt : commit(d, P, witnesses, n, points.size(), false)) tr.write_point(pt);
   trace.mark("openings committed");

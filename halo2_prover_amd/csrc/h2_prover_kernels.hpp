@@ -187,6 +187,92 @@ poly_eval_final_kernel(const U128* __restrict__ partial, uint32_t blocks_per_job
   fe_store<FR>(out + 2 * (size_t)q, acc);
 }
 
+// ---- several synthetic divisions / prefix products in ONE launch sequence (grid.y = job) -------------------------------
+// The same three-kernel scans as h2_poly.hpp (chunk values, log-step scan of <= 1024 chunk values in one block,
+// recurrence inside every chunk), for independent jobs: the opening witnesses of the GWC points, the permutation
+// sets' grand products.  Each scan is a latency chain on 16 waves; side by side they cost what one costs.
+constexpr int SCAN_MAX_JOBS = 8;
+constexpr uint32_t SCAN_CHUNKS = 1024;
+struct ScanBatch {
+  const U128* a[SCAN_MAX_JOBS];
+  U128* out[SCAN_MAX_JOBS];
+  F z[SCAN_MAX_JOBS];        // division only: the point
+  F w[SCAN_MAX_JOBS];        // division only: z^L
+};
+// mode 0: q = (a - a(z)) / (X - z) (suffix sums with weights); mode 1: out[i] = prod_{j < i} a[j]
+static __global__ void __launch_bounds__(64)
+scan_chunk_kernel(ScanBatch B, int mode, uint32_t n, uint32_t L, uint32_t C, U128* __restrict__ H) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, job = blockIdx.y;
+  if (c >= C) return;
+  const U128* a = B.a[job];
+  const uint32_t lo = c * L, hi = min(n, lo + L);
+  F acc;
+  if (mode == 0) {
+    acc = F::zero();
+    const F z = B.z[job];
+    for (uint32_t i = hi; i-- > lo;) acc = fe_add(fe_mul(acc, z), fe_load<FR>(a + 2 * (size_t)i));
+  } else {
+    acc = F::one();
+    for (uint32_t i = lo; i < hi; i++) acc = fe_mul(acc, fe_load<FR>(a + 2 * (size_t)i));
+  }
+  fe_store<FR>(H + 2 * ((size_t)job * SCAN_CHUNKS + c), acc);
+}
+static __global__ void __launch_bounds__(1024)
+scan_block_kernel(ScanBatch B, int mode, uint32_t C, const U128* __restrict__ H, U128* __restrict__ G) {
+  __shared__ U128 lds[2 * SCAN_CHUNKS];
+  const uint32_t c = threadIdx.x, job = blockIdx.x;
+  H += 2 * (size_t)job * SCAN_CHUNKS;
+  G += 2 * (size_t)job * SCAN_CHUNKS;
+  if (mode == 0) {
+    F y = c < C ? fe_load<FR>(H + 2 * c) : F::zero();
+    F wp = B.w[job];
+    for (uint32_t s = 1; s < C; s <<= 1) {
+      fe_store<FR>(lds + 2 * c, y);
+      __syncthreads();
+      if (c + s < C) y = fe_add(y, fe_mul(wp, fe_load<FR>(lds + 2 * (c + s))));
+      __syncthreads();
+      wp = fe_mul(wp, wp);
+    }
+    fe_store<FR>(lds + 2 * c, y);
+    __syncthreads();
+    if (c < C) fe_store<FR>(G + 2 * c, c + 1 < C ? fe_load<FR>(lds + 2 * (c + 1)) : F::zero());
+  } else {
+    F y = c < C ? fe_load<FR>(H + 2 * c) : F::one();
+    for (uint32_t s = 1; s < C; s <<= 1) {
+      fe_store<FR>(lds + 2 * c, y);
+      __syncthreads();
+      if (c >= s) y = fe_mul(y, fe_load<FR>(lds + 2 * (c - s)));
+      __syncthreads();
+    }
+    fe_store<FR>(lds + 2 * c, y);
+    __syncthreads();
+    if (c < C) fe_store<FR>(G + 2 * c, c > 0 ? fe_load<FR>(lds + 2 * (c - 1)) : F::one());
+  }
+}
+static __global__ void __launch_bounds__(64)
+scan_apply_kernel(ScanBatch B, int mode, uint32_t n, uint32_t L, uint32_t C, const U128* __restrict__ G) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, job = blockIdx.y;
+  if (c >= C) return;
+  const U128* a = B.a[job];
+  U128* out = B.out[job];
+  const uint32_t lo = c * L, hi = min(n, lo + L);
+  F cur = fe_load<FR>(G + 2 * ((size_t)job * SCAN_CHUNKS + c));
+  if (mode == 0) {
+    const F z = B.z[job];
+    for (uint32_t i = hi; i-- > lo;) {
+      cur = fe_add(fe_mul(cur, z), fe_load<FR>(a + 2 * (size_t)i));
+      if (i >= 1) fe_store<FR>(out + 2 * (size_t)(i - 1), cur);
+    }
+    if (c == C - 1) fe_store<FR>(out + 2 * (size_t)(n - 1), F::zero());
+  } else {
+    for (uint32_t i = lo; i < hi; i++) {
+      const F x = fe_load<FR>(a + 2 * (size_t)i);
+      fe_store<FR>(out + 2 * (size_t)i, cur);
+      cur = fe_mul(cur, x);
+    }
+  }
+}
+
 // ---- the quotient numerator as a straight-line program -----------------------------------------------------------------
 // operand word: bits 31..30 = kind (0 slot, 1 constant, 2 column); slot / constant: index in bits 29..0;
 // column: index in bits 29..8, rotation + 128 in bits 7..0.  op_dst: op in bits 31..24 (0 add, 1 sub, 2 mul), slot in 23..0.
