@@ -2,6 +2,7 @@
 #include "h2_curve_ops.hpp"
 #include "h2_msm.hpp"
 #include "h2_ntt.hpp"
+#include "h2_ntt29.hpp"
 #include "h2_poly.hpp"
 
 #include <cstring>
@@ -23,10 +24,16 @@ using CV = VESTA_CURVE;
 using FS = typename CV::Scalar;
 using FB = typename CV::Base;
 
+// H2_TUNE_NTT32 (tools/ only): the 32-bit-limb pass kernel of h2_ntt.hpp instead of the 29-bit one, for A/B timing
+bool ntt_use_32() {
+  static const bool v = getenv("H2_TUNE_NTT32") != nullptr;
+  return v;
+}
 hipError_t kernel_setup() {
   hipError_t e = msm_kernel_setup<CV>();
   if (e != hipSuccess) return e;
-  return ntt_kernel_setup<FS>();
+  if ((e = ntt_kernel_setup<FS>()) != hipSuccess) return e;
+  return ntt29_kernel_setup<FS>();
 }
 hipError_t table_build(const void* d_bases, void* d_table, uint32_t n, const MsmGeom& g, uint32_t* d_bad, hipStream_t s) {
   hipLaunchKernelGGL(msm_table_kernel<CV>, dim3((n + 255) / 256), dim3(256), 0, s, (const U128*)d_bases,
@@ -68,13 +75,15 @@ hipError_t points_sum(const void* d_in_jac, void* d_out_jac, uint32_t groups, ui
 hipError_t ntt_twiddles(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s) {
   Fe<FS> w;
   memcpy(w.v, omega, 32);
-  return ntt_build_twiddles<FS>((U128*)d_tw, w, log_n, s);
+  if (ntt_use_32()) return ntt_build_twiddles<FS>((U128*)d_tw, w, log_n, s);
+  return ntt29_build_twiddles<FS>((U128*)d_tw, w, log_n, s);
 }
 hipError_t ntt_launch_(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m, hipStream_t s,
                        const uint64_t* scale) {
   Fe<FS> sc;
   if (scale) memcpy(sc.v, scale, 32);
-  return ntt_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s, scale ? &sc : nullptr);
+  if (ntt_use_32()) return ntt_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s, scale ? &sc : nullptr);
+  return ntt29_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s, scale ? &sc : nullptr);
 }
 hipError_t poly_scale(void* d_a, size_t total, const uint64_t c[4], hipStream_t s) {
   Fe<FS> cv;

@@ -693,6 +693,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   uint32_t lq = 0;
   while ((1u << lq) < span && lq < 4) lq++;
   while (lq > 0 && (ws.K << lq) > 40960) lq--;
+  if (const char* ov = getenv("H2_TUNE_LQ")) lq = (uint32_t)atoi(ov);   // tuning experiments only (tools/)
   uint32_t lg = lq + 2;
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block

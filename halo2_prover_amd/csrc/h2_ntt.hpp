@@ -14,6 +14,8 @@
 // position directly, so no bit-reversal sweep over HBM is needed.  Per pass the algorithmic
 // HBM traffic is one read and one write of the column (64 B per element).
 #pragma once
+#include <cstdlib>
+
 #include "h2_field.hpp"
 
 namespace h2 {
@@ -28,6 +30,7 @@ struct NttPass {
   uint32_t log_r2;     // radix of pass 1 when there are three passes, else 0
   uint32_t is_final;
   uint32_t has_scale;  // final pass multiplies every output by `scale` (EvaluationDomain::ifft's n^-1)
+  uint32_t tw_global;  // 29-bit kernel: radix twiddles read from the table in global memory (L1/L2) instead of LDS
 };
 
 __device__ __forceinline__ uint32_t h2_bitrev(uint32_t x, uint32_t bits) {
@@ -227,6 +230,10 @@ constexpr uint32_t NTT_MAX_LOG_R = 10;  // R <= 1024: tile R*2 elements = 64 KiB
 
 inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R) {
   NttPlan pl{};
+  static const int tune_r = getenv("H2_TUNE_NTT_MAXR") ? atoi(getenv("H2_TUNE_NTT_MAXR")) : 0;     // tools/ only
+  static const int tune_c9 = getenv("H2_TUNE_NTT_LC9") ? atoi(getenv("H2_TUNE_NTT_LC9")) : -1;
+  static const int tune_c = getenv("H2_TUNE_NTT_LC") ? atoi(getenv("H2_TUNE_NTT_LC")) : -1;
+  if (tune_r > 0) max_log_r = (uint32_t)tune_r;
   uint32_t np = log_n == 0 ? 1 : (log_n + max_log_r - 1) / max_log_r;
   if (np > 3) np = 3;  // callers reject log_n > 30
   uint32_t radix[3] = {0, 0, 0};
@@ -250,6 +257,8 @@ inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R)
     // other waits at a barrier): 2 columns for R >= 512, 4 below (measured: R = 1024 x 4 columns, one block per CU,
     // is 13 % slower on the 2^19 transforms; R = 256 x 2 columns is 5-30 % slower than x 4 on the 2^16 ones)
     uint32_t lc = radix[p] >= 9 ? 1 : 2;
+    if (radix[p] >= 9 && tune_c9 >= 0) lc = (uint32_t)tune_c9;
+    if (radix[p] < 9 && tune_c >= 0) lc = (uint32_t)tune_c;
     if (P.is_final) {
       if (lc > P.log_r1) lc = P.log_r1;
     } else {
