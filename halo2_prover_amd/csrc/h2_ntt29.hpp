@@ -123,13 +123,16 @@ ntt29_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U12
       twl1[i] = t[1];
     }
   // load the tile, bit-reversing j on the way in; the API's bytes are read as they are (x 2^256 = R' form of x / 32)
+  // (four elements per thread: unrolled so that the four loads are in flight together)
   if (!P.is_final) {
+#pragma unroll 4
     for (uint32_t e = tid; e < RC; e += nthr) {
       const uint32_t cc = e & (C - 1), j = e >> P.log_c;
       const U128* g = src + 2 * (in_base + (uint64_t)j * in_j_stride + cc);
       lds_put((h2_bitrev(j, P.log_r) << P.log_c) + cc, fe29_unpack(fe_load<FP>(g)));
     }
   } else {
+#pragma unroll 4
     for (uint32_t e = tid; e < RC; e += nthr) {
       const uint32_t j = e & (R - 1), cc = e >> P.log_r;
       const U128* g = src + 2 * (in_base + (uint64_t)cc * in_c_stride + j);

@@ -169,16 +169,17 @@ struct Dev {
   const CurveOps* ops;
   std::vector<std::pair<void*, size_t>> live;                 // everything handed out, freed by the owner's destructor
   std::vector<std::vector<uint8_t>> staged;                   // host buffers of in-flight uploads (kept until sync)
-  // size-keyed cache of freed blocks: hipMalloc / hipFree synchronise the device, a proof needs ~60 buffers
-  static std::multimap<size_t, void*>& cache() {
-    static auto* m = new std::multimap<size_t, void*>();   // never destroyed: keys cached until process exit release into it
+  // cache of freed blocks keyed by (device, size): hipMalloc / hipFree synchronise the device, a proof needs ~60 buffers
+  using BlockKey = std::pair<int, size_t>;
+  static std::multimap<BlockKey, void*>& cache() {
+    static auto* m = new std::multimap<BlockKey, void*>();   // never destroyed: keys cached until process exit release into it
     return *m;
   }
   explicit Dev(DevCtx* ctx) : c(ctx), s(ctx->stream), ops(ops_of(H2_BN254)) {}
   void* alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     void* p = nullptr;
-    auto it = cache().find(bytes);
+    auto it = cache().find(BlockKey{c->device, bytes});
     if (it != cache().end()) {
       p = it->second;
       cache().erase(it);
@@ -195,13 +196,13 @@ struct Dev {
   Col col(size_t elems) { return (Col)alloc(elems * 32); }
   // give everything back to the cache (the stream is in order: a later user of the block queues behind this one)
   void release_all() {
-    for (auto& b : live) cache().insert({b.second, b.first});
+    for (auto& b : live) cache().insert({BlockKey{c->device, b.second}, b.first});
     live.clear();
   }
   void release(void* p) {
     for (size_t i = 0; i < live.size(); i++)
       if (live[i].first == p) {
-        cache().insert({live[i].second, p});
+        cache().insert({BlockKey{c->device, live[i].second}, p});
         live.erase(live.begin() + i);
         return;
       }
@@ -1837,7 +1838,10 @@ void h2_prover_shutdown(void) {
     (void)h2_bases_release(p.h_gl);
   }
   g_params.clear();
-  for (auto& kv : Dev::cache()) (void)hipFree(kv.second);
+  for (auto& kv : Dev::cache()) {
+    DeviceGuard dg(kv.first.first);
+    (void)hipFree(kv.second);
+  }
   Dev::cache().clear();
 }
 

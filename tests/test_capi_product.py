@@ -308,3 +308,25 @@ def test_key_cache_changes_nothing_but_the_time(h2, lib):
         assert c_verify(lib, p6, want, POSEIDON_INPUT, 2) == (0, 1)
     finally:
         lib.h2_key_cache(old)
+
+
+@pytest.mark.gpu
+def test_end_to_end_like_the_references_own_tests(h2, lib):
+    """The reference's two real prove + verify tests, through the C ABI: arithmetic_circuit.rs:334-351 (k = 8, random
+    SRS, OsRng) and poseidon_circuit.rs:312-352 (K = 7, random message) -- setup, keygen on the empty circuit, prove,
+    verify must say Ok"""
+    rnd = random.Random()
+    p8 = c_setup(lib, 8, None)
+    x, y, c = rnd.randrange(1 << 15), rnd.randrange(1 << 15), rnd.randrange(1 << 30)
+    js = '{"x":%d,"y":%d,"constant":%d,"z":%d}' % (x, y, c, x * x * y * y + c)
+    proof = c_prove(lib, p8, js, 1, None)
+    assert c_verify(lib, p8, proof, js, 1) == (0, 1)
+    p7 = c_setup(lib, 7, None)
+    msg = [rnd.randrange(1 << 64), rnd.randrange(1 << 64)]
+    out = ctypes.create_string_buffer(128)
+    n = ctypes.c_size_t(0)
+    assert lib.h2_simulate(('{"x":[%d,%d]}' % tuple(msg)).encode(), 2, out, 128, ctypes.byref(n)) == 0
+    js = '{"x":[%d,%d],"output":"%s"}' % (msg[0], msg[1], out.value.decode())
+    proof = c_prove(lib, p7, js, 2, None)
+    assert c_verify(lib, p7, proof, js, 2) == (0, 1)
+    assert c_verify(lib, p8, proof, js, 2) == (0, 0)                    # another SRS
