@@ -30,6 +30,8 @@ def needs_build():
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return OUT
+    if os.environ.get("H2_BUILD_TUNING"):          # the sweep knobs of csrc/h2_tune.hpp (tools/sweep_*.sh): not a product build
+        extra_flags = tuple(extra_flags) + ("-DH2_TUNING",)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     jobs = []

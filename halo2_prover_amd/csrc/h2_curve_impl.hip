@@ -3,6 +3,7 @@
 #include "h2_msm.hpp"
 #include "h2_ntt.hpp"
 #include "h2_ntt29.hpp"
+#include "h2_tune.hpp"
 #include "h2_poly.hpp"
 
 #include <cstring>
@@ -24,9 +25,9 @@ using CV = VESTA_CURVE;
 using FS = typename CV::Scalar;
 using FB = typename CV::Base;
 
-// H2_TUNE_NTT32 (tools/ only): the 32-bit-limb pass kernel of h2_ntt.hpp instead of the 29-bit one, for A/B timing
+// H2_TUNE_NTT32 (tuning builds only, h2_tune.hpp): the 32-bit-limb pass kernel of h2_ntt.hpp instead of the 29-bit one, for A/B timing
 bool ntt_use_32() {
-  static const bool v = getenv("H2_TUNE_NTT32") != nullptr;
+  static const bool v = tune_int("H2_TUNE_NTT32", 0) != 0;
   return v;
 }
 hipError_t kernel_setup() {

@@ -31,6 +31,7 @@
 #pragma once
 #include "h2_curve29.hpp"
 #include "h2_curve_quad.hpp"
+#include "h2_tune.hpp"
 #include <cstdlib>
 
 namespace h2 {
@@ -61,7 +62,7 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
   // save additions in the accumulate kernel (W = ceil(256 / c)) but every bucket costs ~16 point operations in the
   // tail, so the best width is log2 n - 3 up to 2^16 and log2 n - 4 above
   int c = (int)lg - (lg <= 16 ? 3 : 4);
-  if (const char* ov = getenv("H2_TUNE_C")) c = atoi(ov);   // tuning experiments only (tools/), never set in product runs
+  c = tune_int("H2_TUNE_C", c);             // tuning builds only (h2_tune.hpp)
   if (c < 6) c = 6;
   if (c > (int)MSM_MAX_C) c = (int)MSM_MAX_C;
   MsmGeom g{};
@@ -693,7 +694,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   uint32_t lq = 0;
   while ((1u << lq) < span && lq < 4) lq++;
   while (lq > 0 && (ws.K << lq) > 40960) lq--;
-  if (const char* ov = getenv("H2_TUNE_LQ")) lq = (uint32_t)atoi(ov);   // tuning experiments only (tools/)
+  lq = (uint32_t)tune_int("H2_TUNE_LQ", (int)lq);   // tuning builds only (h2_tune.hpp)
   uint32_t lg = lq + 2;
   ws.log_g = lg;
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block

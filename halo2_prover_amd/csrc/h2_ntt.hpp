@@ -14,9 +14,8 @@
 // position directly, so no bit-reversal sweep over HBM is needed.  Per pass the algorithmic
 // HBM traffic is one read and one write of the column (64 B per element).
 #pragma once
-#include <cstdlib>
-
 #include "h2_field.hpp"
+#include "h2_tune.hpp"
 
 namespace h2 {
 
@@ -230,9 +229,9 @@ constexpr uint32_t NTT_MAX_LOG_R = 10;  // R <= 1024: tile R*2 elements = 64 KiB
 
 inline NttPlan ntt_make_plan(uint32_t log_n, uint32_t max_log_r = NTT_MAX_LOG_R) {
   NttPlan pl{};
-  static const int tune_r = getenv("H2_TUNE_NTT_MAXR") ? atoi(getenv("H2_TUNE_NTT_MAXR")) : 0;     // tools/ only
-  static const int tune_c9 = getenv("H2_TUNE_NTT_LC9") ? atoi(getenv("H2_TUNE_NTT_LC9")) : -1;
-  static const int tune_c = getenv("H2_TUNE_NTT_LC") ? atoi(getenv("H2_TUNE_NTT_LC")) : -1;
+  static const int tune_r = tune_int("H2_TUNE_NTT_MAXR", 0);     // tuning builds only (h2_tune.hpp)
+  static const int tune_c9 = tune_int("H2_TUNE_NTT_LC9", -1);
+  static const int tune_c = tune_int("H2_TUNE_NTT_LC", -1);
   if (tune_r > 0) max_log_r = (uint32_t)tune_r;
   uint32_t np = log_n == 0 ? 1 : (log_n + max_log_r - 1) / max_log_r;
   if (np > 3) np = 3;  // callers reject log_n > 30

@@ -225,7 +225,7 @@ inline size_t ntt29_lds_bytes(const NttPass& P) {
 // a tile that leaves room for a second block on the CU only without its radix twiddles reads them from global memory
 // (the 16 KB table of a 1024-row pass stays in the vector L1 / L2)
 inline bool ntt29_tw_global(const NttPass& P) {
-  static const int tune = getenv("H2_TUNE_NTT_TWG") ? atoi(getenv("H2_TUNE_NTT_TWG")) : -1;     // tools/ only
+  static const int tune = tune_int("H2_TUNE_NTT_TWG", -1);     // tuning builds only (h2_tune.hpp)
   if (tune >= 0) return tune != 0;
   const size_t rc = (size_t)1 << (P.log_r + P.log_c), r = (size_t)1 << P.log_r;
   const size_t with = rc * 36 + (r / 2) * 32, without = rc * 36;

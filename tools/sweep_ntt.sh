@@ -1,5 +1,5 @@
 #!/bin/bash
-# NTT tile sweep (tools only): prints phases_ms.ntt of the bench step for several tile configurations
+# NTT tile sweep (needs a tuning build: H2_BUILD_TUNING=1 python -m halo2_prover_amd.build --force): prints phases_ms.ntt of the bench step for several tile configurations
 run() { env "$@" python bench.py --steps 5 --no-proof --no-cpu-baseline --no-extras 2>/dev/null | VV="$*" python -c '
 import json, os, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
