@@ -32,6 +32,7 @@
 #include "h2_curve29.hpp"
 #include "h2_curve_quad.hpp"
 #include "h2_tune.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace h2 {
@@ -307,6 +308,18 @@ msm_scatter_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict_
   }
 }
 
+// Entries per accumulate thread, decided ON THE DEVICE from the number of entries the sort actually produced
+// (E = offsets[K]): the host sizes T for the worst case (every window of every scalar non-zero), but the columns of a
+// real proof are mostly zeros (a Poseidon witness is ~60 rows of 65 536, fixed columns likewise): with the host's T a
+// sparse launch put 64 dependent additions on each of a few hundred threads of an idle GPU (1.9 ms for keygen's 16
+// sparse columns).  Every kernel that cuts the sorted list into chunks calls this with the same arguments.  Never
+// above the host's T, so the chunk count stays within the arrays sized for it.
+__device__ __forceinline__ uint32_t msm_effective_t(uint32_t E, uint32_t t_host) {
+  uint32_t t = (E + MSM_CHUNK_WAVES * 65536u - 1) / (MSM_CHUNK_WAVES * 65536u);
+  if (t < 8) t = 8;
+  return t < t_host ? t : t_host;
+}
+
 // ---- accumulate: every thread adds T consecutive sorted entries ---------------------------------
 template <class CV>
 __device__ __forceinline__ Affine29<CV> msm_fetch(const U128* __restrict__ table, uint32_t entry) {
@@ -322,10 +335,11 @@ template <class CV>
 __global__ void __launch_bounds__(256)
 msm_chunk_kernel(const U128* __restrict__ table, const U128* const* __restrict__ col_tables, uint32_t log_b,
                  const uint32_t* __restrict__ sorted_ref,
-                 const uint32_t* __restrict__ chunk_first, const uint32_t* __restrict__ offsets, size_t K, uint32_t T,
+                 const uint32_t* __restrict__ chunk_first, const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host,
                  uint32_t* __restrict__ bucket_sum, uint32_t* __restrict__ head, uint32_t* __restrict__ tail) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t E = offsets[K];
+  const uint32_t T = msm_effective_t(E, T_host);
   const uint64_t lo64 = (uint64_t)t * T;
   if (lo64 >= E) return;
   const uint32_t lo = (uint32_t)lo64, hi = (uint32_t)min((uint64_t)E, lo64 + T);
@@ -393,12 +407,13 @@ __device__ __forceinline__ Xyzz29<CV> msm_piece(const uint32_t* __restrict__ hea
 // The same pass gives every chunk its first key: chunk_first[j] = key for the chunks that START inside the key's
 // list (each chunk start lies in exactly one non-empty list, so every slot below ceil(E / T) gets one writer).
 static __global__ void __launch_bounds__(256)
-msm_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t* __restrict__ chunk_first,
+msm_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host, uint32_t* __restrict__ chunk_first,
                 uint32_t* __restrict__ hot_slot, uint32_t* __restrict__ tasks /* 2 words each: key, segment */,
                 uint32_t* task_count, uint32_t max_tasks) {
   // long lists (degenerate columns: tens of thousands of chunks under one key) are filled by the whole block
   __shared__ uint32_t long_key[256];
   __shared__ uint32_t n_long;
+  const uint32_t T = msm_effective_t(offsets[K], T_host);
   if (threadIdx.x == 0) n_long = 0;
   __syncthreads();
   const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,11 +456,12 @@ msm_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint
 // task's MSM_HOT_SEG pieces, then a 4-level shuffle tree across the quads
 template <class CV>
 __global__ void __launch_bounds__(64)
-msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const uint32_t* __restrict__ hot_slot,
+msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host, const uint32_t* __restrict__ hot_slot,
                       const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t max_tasks,
                       const uint32_t* __restrict__ head, const uint32_t* __restrict__ tail, uint32_t* __restrict__ hot_part) {
   __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   const uint32_t ntask = min(*task_count, max_tasks);
+  const uint32_t T = msm_effective_t(offsets[K], T_host);
   const uint32_t quad = threadIdx.x >> 2;
   for (uint32_t t = blockIdx.x; t < ntask; t += gridDim.x) {
     const uint32_t key = tasks[2 * t], q = tasks[2 * t + 1];
@@ -464,12 +480,13 @@ msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, uint32_t T, const ui
 // xsum[key], the bucket's point sum.
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T, uint32_t log_g,
+msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host, uint32_t log_g,
                  const uint32_t* __restrict__ bucket_sum, const uint32_t* __restrict__ head,
                  const uint32_t* __restrict__ tail, const uint32_t* __restrict__ hot_slot,
                  const uint32_t* __restrict__ hot_part, uint32_t* __restrict__ xsum) {
   __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   const uint32_t G = 1u << log_g;
+  const uint32_t T = msm_effective_t(offsets[K], T_host);
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t key = gt >> log_g;
   const uint32_t lane = (uint32_t)gt & (G - 1);
@@ -687,6 +704,12 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   }
   ws.T = (uint32_t)T;
   ws.nchunks = (ws.E + T - 1) / T;
+  {
+    // the device may cut finer than T when the sort produced fewer entries than the worst case (msm_effective_t):
+    // never more chunks than ceil(E / 8) nor than MSM_CHUNK_WAVES waves per SIMD -- size arrays and grid for that
+    const size_t fine = std::min<size_t>((ws.E + 7) / 8, (size_t)MSM_CHUNK_WAVES * 65536 + 1);
+    if (ws.nchunks < fine) ws.nchunks = fine;
+  }
   // pieces per key ~ list length / T + 1
   const double span = (double)g.W * (double)n / (double)g.B / (double)T + 1.0;
   // quads per key in the fix-up: no more than the pieces need, and few enough that the launch stays around
@@ -806,7 +829,7 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
                      (const U128* const*)d_tables, log_b, sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   if (ev_tail) (void)hipEventRecord(ev_tail, stream);   // from here on only small-grid kernels: other streams may fill the chip
-  hipLaunchKernelGGL(msm_hot_reduce_kernel<CV>, dim3(1024), dim3(64), 0, stream, offsets, ws.T, hot_slot, hot_tasks,
+  hipLaunchKernelGGL(msm_hot_reduce_kernel<CV>, dim3(1024), dim3(64), 0, stream, offsets, ws.K, ws.T, hot_slot, hot_tasks,
                      misc, ws.max_tasks, head, tail, hot_part);
   const size_t fix_threads = ws.K << ws.log_g;
   hipLaunchKernelGGL(msm_fixup_kernel<CV>, dim3((unsigned)((fix_threads + 255) / 256)), dim3(256), 0, stream, offsets,

@@ -23,6 +23,7 @@
 #include <set>
 
 #include "h2_circuits.hpp"
+#include "h2_curve.hpp"
 #include "h2_internal.hpp"
 #include "h2_pairing.hpp"
 #include "h2_poly.hpp"
@@ -344,6 +345,10 @@ struct Params {
   G1 g0;
   bn::G2 g2, s_g2;
   std::array<uint8_t, 64> digest{};
+  // [delta^j] commit_lagrange(w^i): the commitment of the IDENTITY permutation's column j -- a property of the SRS, not
+  // of a circuit.  A circuit's sigma_j differs from it in the few cells its copy constraints move, so its
+  // commitment is this point plus a sparse MSM (keygen would otherwise commit to 7 dense columns on every call)
+  mutable std::vector<G1> sigma_identity;
 };
 std::vector<Params> g_params;       // small LRU: the UI keeps one SRS, tests a few
 
@@ -581,6 +586,44 @@ Fr fr_delta() {   // DELTA = 7^(2^28): generator of the coset structure of the p
 }
 
 // m columns of n scalars -> m commitments (affine, canonical coordinates)
+// host group law on G1 (the same XYZZ templates as the kernels, host instantiation): a handful of operations per keygen
+using HX = Xyzz<BN254_CURVE>;
+HX hx_of(const G1& p) {
+  if (p.inf) return HX::identity();
+  return xyzz_from_affine(Affine<BN254_CURVE>{p.x.v, p.y.v});
+}
+std::vector<G1> hx_to_affine(const std::vector<HX>& pts) {       // one shared inversion
+  std::vector<Fq> z(pts.size()), pre(pts.size());
+  Fq acc = Fq::one();
+  for (size_t j = 0; j < pts.size(); j++) {
+    z[j] = Fq(pts[j].zzz);
+    pre[j] = acc;
+    if (!pts[j].is_identity()) acc *= z[j];
+  }
+  Fq inv = acc.inv();
+  std::vector<G1> out(pts.size());
+  for (size_t j = pts.size(); j-- > 0;) {
+    if (pts[j].is_identity()) continue;
+    const Fq zi3 = inv * pre[j];                                  // 1 / zzz
+    inv *= z[j];
+    const Fq zi = zi3 * Fq(pts[j].zz);                            // zz / zzz = 1 / z
+    out[j].x = Fq(pts[j].x) * zi.sqr();
+    out[j].y = Fq(pts[j].y) * zi3;
+    out[j].inf = false;
+  }
+  return out;
+}
+HX hx_mul(const Fr& k, const HX& p) {
+  uint8_t kb[32];
+  k.to_le_bytes(kb);
+  HX r = HX::identity();
+  for (int i = 255; i >= 0; i--) {
+    r = xyzz_double(r);
+    if ((kb[i >> 3] >> (i & 7)) & 1) r = xyzz_add(r, p);
+  }
+  return r;
+}
+
 // `split` < m: columns [0, split) commit against g_lagrange and [split, m) against g IN THE SAME LAUNCH (commitments
 // that do not wait for each other: the permutation products and the RNG-drawn random polynomial)
 std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange, size_t split = ~(size_t)0) {
@@ -673,6 +716,7 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
     hip_ok(d.ops->poly_powers(K.omega_col, n, 1, w, d.s), "poly_powers");
   }
   const Fr delta = fr_delta();
+  std::vector<std::pair<std::pair<int, uint32_t>, Fr>> moved;     // (permutation column, row) -> its sigma value
   {
     std::vector<std::pair<Col, Fr>> t(1);
     Fr dj = Fr::one();
@@ -689,6 +733,7 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
       if (kv.first.second >= n || kv.second.second >= n) fail(H2_EINVAL, "k too small for this circuit");
       refs.push_back({(uint32_t)kv.first.first, kv.first.second});
       vals.push_back(delta.pow_u64((uint64_t)kv.second.first) * D.omega.pow_u64(kv.second.second));
+      moved.push_back({kv.first, vals.back()});
     }
     if (!refs.empty()) {
       const pk::CellRef* d_refs = (const pk::CellRef*)d.upload(refs.data(), refs.size() * sizeof(pk::CellRef));
@@ -698,9 +743,38 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
       hip_ok(hipGetLastError(), "scatter_cells_kernel");
     }
   }
-  // commitments of the fixed + sigma columns (one MSM phase), their coefficient and extended forms
+  // commitments of the fixed + sigma columns, their coefficient and extended forms.  sigma_j = (identity permutation's
+  // column j) + (the cells the copy constraints move): the first part's commitment is [delta^j] commit(w^i), kept
+  // with the SRS; the second is sparse.  One MSM launch over nf + np SPARSE columns instead of np dense ones.
   trace.mark("columns built");
-  std::vector<G1> commits = commit(d, P, lag, n, nf + np, true);
+  if (P.sigma_identity.size() < np) {
+    const G1 c_omega = commit(d, P, K.omega_col, n, 1, true)[0];
+    std::vector<HX> pts;
+    HX cur = hx_of(c_omega);
+    for (size_t j = 0; j < std::max<size_t>(np, 8); j++) {
+      pts.push_back(cur);
+      cur = hx_mul(delta, cur);
+    }
+    P.sigma_identity = hx_to_affine(pts);
+    trace.mark("identity permutation committed");
+  }
+  std::vector<G1> commits;
+  {
+    Col sparse = d.col((nf + np) * (size_t)n);
+    d.copy(sparse, K.fixed_values, nf * (size_t)n * 32);
+    std::vector<SparseCol> diff(np);
+    for (auto& kv : moved) {
+      const int j = kv.first.first;
+      diff[j][kv.first.second] = kv.second - delta.pow_u64((uint64_t)j) * D.omega.pow_u64(kv.first.second);
+    }
+    d.fill_sparse(sparse + 2 * nf * (size_t)n, n, diff);
+    commits = commit(d, P, sparse, n, nf + np, true);
+    d.release(sparse);
+    std::vector<HX> sums;
+    for (size_t j = 0; j < np; j++) sums.push_back(xyzz_add(hx_of(P.sigma_identity[j]), hx_of(commits[nf + j])));
+    const std::vector<G1> sig = hx_to_affine(sums);
+    for (size_t j = 0; j < np; j++) commits[nf + j] = sig[j];
+  }
   trace.mark("fixed + sigma committed");
   K.fixed_commitments.assign(commits.begin(), commits.begin() + nf);
   K.sigma_commitments.assign(commits.begin() + nf, commits.end());
