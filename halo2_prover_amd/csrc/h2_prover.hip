@@ -558,6 +558,18 @@ struct ColumnMap {
   int advice0, fixed0, instance0, sigma0, z0, l0, l_last, l_blind, xcol, tinv, count;
 };
 
+// what depends on the domain alone -- (k, constraint degree, blinding factors) -- and not on a circuit's columns or an
+// SRS: w^i, the polynomial X and the three Lagrange-basis combinations l_0, l_last, l_blind on the extended coset,
+// 1 / (X^n - 1).  Kept for the life of the process (a handful of shapes), shared by every key of that shape.
+struct DomainKit {
+  int device;
+  uint32_t k, ext_k;
+  int bf;
+  std::unique_ptr<Dev> dev;
+  Col omega_col = nullptr, xcol_ext = nullptr, basis_ext = nullptr, tinv = nullptr;
+};
+std::vector<std::unique_ptr<DomainKit>> g_kits;
+
 struct ProvingKey {
   std::unique_ptr<Circuit> circuit;
   std::unique_ptr<Domain> dom;
@@ -672,6 +684,61 @@ void coeff_to_extended(Dev& d, const Domain& D, Col in, size_t m, Col out) {
   d.ntt(out, m, D.ext_omega, D.ext_k);
 }
 
+const DomainKit& domain_kit(const Domain& D, int bf, DevCtx* ctx) {
+  for (auto& kp : g_kits)
+    if (kp->device == ctx->device && kp->k == D.k && kp->ext_k == D.ext_k && kp->bf == bf) return *kp;
+  auto kit = std::make_unique<DomainKit>();
+  kit->device = ctx->device;
+  kit->k = D.k;
+  kit->ext_k = D.ext_k;
+  kit->bf = bf;
+  kit->dev = std::make_unique<Dev>(ctx);
+  Dev& d = *kit->dev;
+  const uint32_t n = D.n;
+  uint64_t w[4];
+  // a ones column = the NTT of (1, 0, 0, ...) (every evaluation of the constant polynomial 1 is 1); then a[i] *= w^i
+  kit->omega_col = d.col(n);
+  {
+    std::vector<SparseCol> c1(1);
+    c1[0][0] = Fr::one();
+    d.fill_sparse(kit->omega_col, n, c1);
+    d.ntt(kit->omega_col, 1, D.omega, D.k);
+    Dev::limbs(D.omega, w);
+    hip_ok(d.ops->poly_powers(kit->omega_col, n, 1, w, d.s), "poly_powers");
+  }
+  // l_0, l_last, l_blind: Lagrange -> coefficients -> extended coset
+  {
+    Col basis = d.col(3 * (size_t)n);
+    std::vector<SparseCol> b(3);
+    b[0][0] = Fr::one();
+    b[1][n - bf - 1] = Fr::one();
+    for (uint32_t r = n - bf; r < n; r++) b[2][r] = Fr::one();
+    d.fill_sparse(basis, n, b);
+    d.ntt(basis, 3, D.omega_inv, D.k, &D.n_inv);
+    kit->basis_ext = d.col(3 * (size_t)D.en);
+    hipLaunchKernelGGL(pk::coset_extend_kernel, dim3((D.en + 255) / 256, 3u), dim3(256), 0, d.s, basis, (size_t)n,
+                       kit->basis_ext, n, D.en, D.zeta.v, D.zeta.sqr().v);
+    hip_ok(hipGetLastError(), "coset_extend_kernel");
+    d.ntt(kit->basis_ext, 3, D.ext_omega, D.ext_k);
+    d.release(basis);
+  }
+  // the polynomial X on the coset: zeta w_ext^i
+  kit->xcol_ext = d.col(D.en);
+  {
+    std::vector<SparseCol> c1(1);
+    c1[0][0] = D.zeta;
+    d.fill_sparse(kit->xcol_ext, D.en, c1);
+    d.ntt(kit->xcol_ext, 1, D.ext_omega, D.ext_k);                  // (zeta, zeta, ...)
+    Dev::limbs(D.ext_omega, w);
+    hip_ok(d.ops->poly_powers(kit->xcol_ext, D.en, 1, w, d.s), "poly_powers");
+  }
+  kit->tinv = d.upload_frs(D.t_evaluations);
+  d.sync();
+  if (g_kits.size() >= 8) g_kits.erase(g_kits.begin());
+  g_kits.push_back(std::move(kit));
+  return *g_kits.back();
+}
+
 std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> circuit, DevCtx* ctx) {
   Trace trace("keygen");
   auto pkp = std::make_unique<ProvingKey>();
@@ -701,20 +768,12 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   K.fixed_values = lag;
   K.sigma_values = lag + 2 * nf * (size_t)n;
   d.fill_sparse(K.fixed_values, n, fixed);
-  // omega_col[i] = w^i; sigma_j[i] = delta^j w^i except on the cells the copy constraints permute
-  K.omega_col = d.col(n);
-  {
-    std::vector<SparseCol> c1(1);
-    c1[0][0] = Fr::one();
-    d.fill_sparse(K.omega_col, n, c1);                              // (1, 0, 0, ...)
-  }
-  // a ones column = the NTT of (1, 0, 0, ...) (every evaluation of the constant polynomial 1 is 1); then a[i] *= w^i
-  d.ntt(K.omega_col, 1, D.omega, D.k);                              // (1, 1, 1, ...)
-  {
-    uint64_t w[4];
-    Dev::limbs(D.omega, w);
-    hip_ok(d.ops->poly_powers(K.omega_col, n, 1, w, d.s), "poly_powers");
-  }
+  // omega_col[i] = w^i (domain kit); sigma_j[i] = delta^j w^i except on the cells the copy constraints permute
+  const DomainKit& kit = domain_kit(D, K.bf, ctx);
+  K.omega_col = kit.omega_col;
+  K.basis_ext = kit.basis_ext;
+  K.xcol_ext = kit.xcol_ext;
+  K.tinv = kit.tinv;
   const Fr delta = fr_delta();
   std::vector<std::pair<std::pair<int, uint32_t>, Fr>> moved;     // (permutation column, row) -> its sigma value
   {
@@ -778,36 +837,15 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   trace.mark("fixed + sigma committed");
   K.fixed_commitments.assign(commits.begin(), commits.begin() + nf);
   K.sigma_commitments.assign(commits.begin() + nf, commits.end());
-  Col polys = d.col((nf + np + 3) * n);      // + the three Lagrange basis combinations l0, l_last, l_blind
+  Col polys = d.col((nf + np) * n);
   K.fixed_polys = polys;
   K.sigma_polys = polys + 2 * nf * (size_t)n;
-  Col basis = polys + 2 * (nf + np) * (size_t)n;
   d.copy(polys, lag, (nf + np) * (size_t)n * 32);
-  {
-    std::vector<SparseCol> b(3);
-    b[0][0] = Fr::one();
-    b[1][n - K.bf - 1] = Fr::one();
-    for (uint32_t r = n - K.bf; r < n; r++) b[2][r] = Fr::one();
-    d.fill_sparse(basis, n, b);
-  }
-  d.ntt(polys, nf + np + 3, D.omega_inv, D.k, &D.n_inv);
-  Col ext = d.col((nf + np + 3) * (size_t)D.en);
+  d.ntt(polys, nf + np, D.omega_inv, D.k, &D.n_inv);
+  Col ext = d.col((nf + np) * (size_t)D.en);
   K.fixed_ext = ext;
   K.sigma_ext = ext + 2 * nf * (size_t)D.en;
-  K.basis_ext = ext + 2 * (nf + np) * (size_t)D.en;
-  coeff_to_extended(d, D, polys, nf + np + 3, ext);
-  // the polynomial X on the coset: zeta w_ext^i
-  K.xcol_ext = d.col(D.en);
-  {
-    std::vector<SparseCol> c1(1);
-    c1[0][0] = D.zeta;
-    d.fill_sparse(K.xcol_ext, D.en, c1);
-    d.ntt(K.xcol_ext, 1, D.ext_omega, D.ext_k);                     // (zeta, zeta, ...)
-    uint64_t w[4];
-    Dev::limbs(D.ext_omega, w);
-    hip_ok(d.ops->poly_powers(K.xcol_ext, D.en, 1, w, d.s), "poly_powers");
-  }
-  K.tinv = d.upload_frs(D.t_evaluations);
+  coeff_to_extended(d, D, polys, nf + np, ext);
   // vk digest
   const std::string s = vk_debug_string(C, D.k, D.ext_k, D.omega, K.fixed_commitments, K.sigma_commitments);
   K.transcript_repr = vk_transcript_repr(s);
@@ -873,9 +911,8 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   const int root = X.mul(numer, X.column(M.tinv, 0));
   X.compile(root);
   K.d_code = (const pk::XInstr*)d.upload(X.code.data(), X.code.size() * sizeof(pk::XInstr));
-  trace.mark("program compiled");
-  d.sync();
-  trace.mark("synchronised");
+  trace.mark("program compiled");     // no synchronisation here: create_proof queues behind keygen's kernels on the same
+                                      // stream, and the staged host copies of the uploads live as long as the key
   if (trace.on) {
     size_t nmul = 0, ncol = 0;
     for (auto& ins : X.code) {
@@ -1907,6 +1944,7 @@ int h2_params_cache_clear(void) {
 // called by h2_shutdown: drop keys, params and the cached device blocks
 void h2_prover_shutdown(void) {
   g_keys.clear();
+  g_kits.clear();
   for (auto& p : g_params) {
     (void)h2_bases_release(p.h_g);
     (void)h2_bases_release(p.h_gl);
