@@ -431,6 +431,9 @@ int h2_shutdown(void) {
       (void)hipEventDestroy(pe.first);
       (void)hipEventDestroy(pe.second);
     }
+    if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
+    for (auto& e : c.side_ev)
+      if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c.stream);
   }
   g_h2.bases.clear();

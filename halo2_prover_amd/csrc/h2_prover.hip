@@ -253,11 +253,25 @@ struct Dev {
                        d_refs, d_vals, (uint32_t)refs.size());
     hip_ok(hipGetLastError(), "scatter_cells_kernel");
   }
-  void ntt(Col a, size_t m, const Fr& omega, uint32_t log_n, const Fr* scale = nullptr) {
+  void ntt(Col a, size_t m, const Fr& omega, uint32_t log_n, const Fr* scale = nullptr, hipStream_t on = nullptr) {
     uint64_t w[4], sc[4];
     limbs(omega, w);
     if (scale) limbs(*scale, sc);
-    st_ok(ntt_enqueue(*c, H2_BN254, a, m, w, log_n, s, scale ? sc : nullptr), "ntt_enqueue");
+    st_ok(ntt_enqueue(*c, H2_BN254, a, m, w, log_n, on ? on : s, scale ? sc : nullptr), "ntt_enqueue");
+  }
+  // the second stream of this context (non-blocking) and three events to hand work back and forth
+  hipStream_t side() {
+    if (!c->side_stream) {
+      hip_ok(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+      for (auto& e : c->side_ev) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
+    }
+    return c->side_stream;
+  }
+  // `to` waits for everything enqueued on `from` so far
+  void order(hipStream_t from, hipStream_t to, int ev) {
+    side();
+    hip_ok(hipEventRecord(c->side_ev[ev], from), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(to, c->side_ev[ev], 0), "hipStreamWaitEvent");
   }
   void lincomb(Col out, uint32_t n, const std::vector<std::pair<Col, Fr>>& terms) {
     bool accumulate = false;
@@ -589,6 +603,11 @@ struct ProvingKey {
   const pk::XInstr* d_code = nullptr;
   size_t nf() const { return (size_t)circuit->num_fixed; }
   size_t np() const { return circuit->permutation_columns.size(); }
+  // the key's transforms may still be running on the second stream when a key that is not kept dies (verify with
+  // the key cache off): its blocks go back to the cache only once that stream is idle
+  ~ProvingKey() {
+    if (dev && dev->c->side_stream) (void)hipStreamSynchronize(dev->c->side_stream);
+  }
 };
 
 Fr fr_delta() {   // DELTA = 7^(2^28): generator of the coset structure of the permutation argument
@@ -677,11 +696,11 @@ std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, 
 }
 
 // coeff (m columns of n, stride n) -> extended-coset evaluations (m columns of en)
-void coeff_to_extended(Dev& d, const Domain& D, Col in, size_t m, Col out) {
-  hipLaunchKernelGGL(pk::coset_extend_kernel, dim3((D.en + 255) / 256, (unsigned)m), dim3(256), 0, d.s, in, (size_t)D.n, out,
-                     D.n, D.en, D.zeta.v, D.zeta.sqr().v);
+void coeff_to_extended(Dev& d, const Domain& D, Col in, size_t m, Col out, hipStream_t on = nullptr) {
+  hipLaunchKernelGGL(pk::coset_extend_kernel, dim3((D.en + 255) / 256, (unsigned)m), dim3(256), 0, on ? on : d.s, in,
+                     (size_t)D.n, out, D.n, D.en, D.zeta.v, D.zeta.sqr().v);
   hip_ok(hipGetLastError(), "coset_extend_kernel");
-  d.ntt(out, m, D.ext_omega, D.ext_k);
+  d.ntt(out, m, D.ext_omega, D.ext_k, nullptr, on);
 }
 
 const DomainKit& domain_kit(const Domain& D, int bf, DevCtx* ctx) {
@@ -805,6 +824,21 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   // commitments of the fixed + sigma columns, their coefficient and extended forms.  sigma_j = (identity permutation's
   // column j) + (the cells the copy constraints move): the first part's commitment is [delta^j] commit(w^i), kept
   // with the SRS; the second is sparse.  One MSM launch over nf + np SPARSE columns instead of np dense ones.
+  // coefficient and extended forms of the fixed + sigma columns on the second stream, beside the commitment below and
+  // the first phases of the proof (create_proof takes the second stream back before it needs them)
+  Col polys = d.col((nf + np) * n);
+  K.fixed_polys = polys;
+  K.sigma_polys = polys + 2 * nf * (size_t)n;
+  Col ext = d.col((nf + np) * (size_t)D.en);
+  K.fixed_ext = ext;
+  K.sigma_ext = ext + 2 * nf * (size_t)D.en;
+  {
+    hipStream_t side = d.side();
+    d.order(d.s, side, 0);
+    hip_ok(hipMemcpyAsync(polys, lag, (nf + np) * (size_t)n * 32, hipMemcpyDeviceToDevice, side), "hipMemcpyAsync(D2D)");
+    d.ntt(polys, nf + np, D.omega_inv, D.k, &D.n_inv, side);
+    coeff_to_extended(d, D, polys, nf + np, ext, side);
+  }
   trace.mark("columns built");
   if (P.sigma_identity.size() < np) {
     const G1 c_omega = commit(d, P, K.omega_col, n, 1, true)[0];
@@ -837,15 +871,6 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   trace.mark("fixed + sigma committed");
   K.fixed_commitments.assign(commits.begin(), commits.begin() + nf);
   K.sigma_commitments.assign(commits.begin() + nf, commits.end());
-  Col polys = d.col((nf + np) * n);
-  K.fixed_polys = polys;
-  K.sigma_polys = polys + 2 * nf * (size_t)n;
-  d.copy(polys, lag, (nf + np) * (size_t)n * 32);
-  d.ntt(polys, nf + np, D.omega_inv, D.k, &D.n_inv);
-  Col ext = d.col((nf + np) * (size_t)D.en);
-  K.fixed_ext = ext;
-  K.sigma_ext = ext + 2 * nf * (size_t)D.en;
-  coeff_to_extended(d, D, polys, nf + np, ext);
   // vk digest
   const std::string s = vk_debug_string(C, D.k, D.ext_k, D.omega, K.fixed_commitments, K.sigma_commitments);
   K.transcript_repr = vk_transcript_repr(s);
@@ -969,6 +994,16 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
     d.fill_sparse(advice_values, n, adv);
   }
   trace.mark("witness uploaded");
+  // Lagrange -> coefficient -> extended coset of the advice and instance columns: they wait for no challenge, so they
+  // run on the context's second stream beside the commit phases (whose MSM tails leave the chip mostly idle); the
+  // permutation products' follow once those exist; the main stream takes everything back before the quotient
+  Col polys = d.col((na + ni + nz) * (size_t)n);
+  Col ext = d.col((na + ni + nz) * (size_t)en);
+  hipStream_t side = d.side();
+  d.order(d.s, side, 0);
+  hip_ok(hipMemcpyAsync(polys, lag, (na + ni) * (size_t)n * 32, hipMemcpyDeviceToDevice, side), "hipMemcpyAsync(D2D)");
+  d.ntt(polys, na + ni, D.omega_inv, D.k, &D.n_inv, side);
+  coeff_to_extended(d, D, polys, na + ni, ext, side);
   for (auto& pt : commit(d, P, advice_values, n, na, true)) tr.write_point(pt);
   trace.mark("advice committed");
   const Fr theta = tr.squeeze_challenge(), beta = tr.squeeze_challenge(), gamma = tr.squeeze_challenge();
@@ -1046,17 +1081,19 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
     hip_ok(d.ops->chacha20_scalars(random_poly, n, 0, key, d.s), "chacha20_scalars");
     (void)rng.fr_random();
   }
+  if (nz) {
+    d.order(d.s, side, 1);                     // the z columns (blinding rows included) are final on the main stream
+    Col zp = polys + 2 * (na + ni) * (size_t)n;
+    hip_ok(hipMemcpyAsync(zp, z_values, nz * (size_t)n * 32, hipMemcpyDeviceToDevice, side), "hipMemcpyAsync(D2D)");
+    d.ntt(zp, nz, D.omega_inv, D.k, &D.n_inv, side);
+    coeff_to_extended(d, D, zp, nz, ext + 2 * (na + ni) * (size_t)en, side);
+  }
   for (auto& pt : commit(d, P, z_values, n, nz + 1, true, nz)) tr.write_point(pt);
   trace.mark("grand products + random poly committed");
 
-  // coefficient forms, then the extended coset
-  Col polys = d.col((na + ni + nz) * (size_t)n);
-  d.copy(polys, lag, (na + ni + nz) * (size_t)n * 32);
-  d.ntt(polys, na + ni + nz, D.omega_inv, D.k, &D.n_inv);
   Col advice_polys = polys, z_polys = polys + 2 * (na + ni) * (size_t)n;
   const Fr y = tr.squeeze_challenge();
-  Col ext = d.col((na + ni + nz) * (size_t)en);
-  coeff_to_extended(d, D, polys, na + ni + nz, ext);
+  d.order(side, d.s, 2);                       // every coefficient and extended form is needed from here on
 
   // the quotient: one program over every extended column
   Col h_ext = d.col(en);
