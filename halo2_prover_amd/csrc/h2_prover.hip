@@ -1743,6 +1743,7 @@ bn::G2 g2_mul(const Fr& k, const bn::G2& pt) {
 struct KeyEntry {
   std::array<uint8_t, 64> digest;
   int circuit;
+  int device;                         // a key's columns live on one GPU
   std::unique_ptr<ProvingKey> key;
 };
 std::vector<KeyEntry> g_keys;
@@ -1760,7 +1761,7 @@ ProvingKey& key_for(const Params& P, int idx, DevCtx* ctx, std::unique_ptr<Provi
   const int slot = circuit_slot(idx);
   if (g_key_cache) {
     for (auto& e : g_keys)
-      if (e.circuit == slot && e.digest == P.digest) {
+      if (e.circuit == slot && e.device == ctx->device && e.digest == P.digest) {
         e.key->params = &P;       // the params list may have been reordered since
         return *e.key;
       }
@@ -1768,7 +1769,7 @@ ProvingKey& key_for(const Params& P, int idx, DevCtx* ctx, std::unique_ptr<Provi
   owner = keygen(P, empty_circuit(slot), ctx);
   if (!g_key_cache) return *owner;
   if (g_keys.size() >= 6) g_keys.erase(g_keys.begin());
-  g_keys.push_back({P.digest, slot, std::move(owner)});
+  g_keys.push_back({P.digest, slot, ctx->device, std::move(owner)});
   return *g_keys.back().key;
 }
 
