@@ -408,7 +408,7 @@ def main():
         if (args.workload == "poseidon" and args.curve == "pallas" and k == 16 and world == 1
                 and pmc.get("source_hash") == source_hash()):
             traffic = pmc["dominant_kernel"]["traffic_bytes_per_launch"]
-            per = next(v for name, v in pmc["kernels"].items() if "ntt_pass_kernel" in name)
+            per = next(v for name, v in pmc["kernels"].items() if "pass_kernel" in name and "ntt" in name)
             ntt_traffic = per["traffic_bytes_per_launch"] * per["launches"] // pmc["steps_profiled"]
             traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc, kernel sources %s, head %s)" % (
                 pmc["source_hash"], pmc.get("git_head", "?"))
