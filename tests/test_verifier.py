@@ -4,7 +4,7 @@
   pairing on its own -- "parity unpinned" for that piece; what pins the verifier as a whole are the proofs recorded
   from the reference's build, below.
 * GPU: the proofs the reference's build produced (tests/golden/, sha256 in SURVEY.md App. B.2) are ACCEPTED -- all three
-  circuits, GWC and SHPLONK; proofs at the recorded k = 11 (and under `slow`, k = 16) hashes are accepted; proofs made
+  circuits, GWC and SHPLONK; proofs at the recorded k = 11 and k = 16 hashes are accepted; proofs made
   with OsRng are accepted; the same proofs with one byte flipped, a wrong public input, a truncated or empty proof or
   another circuit's proof are REJECTED (the reference traps there, utils.rs:150-157; here `False`).
 """
@@ -167,7 +167,7 @@ def test_accepts_fresh_proofs_made_with_os_randomness(h2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [11, pytest.param(16, marks=pytest.mark.slow)])
+@pytest.mark.parametrize("k", [11, 16])
 def test_accepts_the_poseidon_proof_at_the_recorded_hash(h2, k):
     from halo2_prover_amd import prover, verifier as V
     rng = SurveyRng(0)
