@@ -69,7 +69,7 @@ hipError_t to_affine(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s)
   return hipGetLastError();
 }
 hipError_t points_sum(const void* d_in_jac, void* d_out_jac, uint32_t groups, uint32_t count, hipStream_t s) {
-  hipLaunchKernelGGL(points_sum_kernel<CV>, dim3((count + 63) / 64), dim3(64), 0, s, (const U128*)d_in_jac,
+  hipLaunchKernelGGL(points_sum_kernel<CV>, dim3(count), dim3(64), 0, s, (const U128*)d_in_jac,
                      (U128*)d_out_jac, groups, count);
   return hipGetLastError();
 }
