@@ -241,15 +241,17 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
       }
     }
     if (c.tail_wanted && !c.tail_event) H2_TRY(hipEventCreateWithFlags(&c.tail_event, hipEventDisableTiming));
+    void* dst = (char*)d_out + j0 * out_sz;
     hipError_t e = ops->msm_launch(table, per_column ? col_tables : nullptr, (uint32_t)be.n,
                                    (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
-                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1, c.tail_wanted ? c.tail_event : nullptr);
+                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1, c.tail_wanted ? c.tail_event : nullptr,
+                                   affine_out ? nullptr : dst);
     c.tail_recorded = c.tail_wanted;
     if (e != hipSuccess) return dev_fail(e, "msm_launch");
-    const void* src = (char*)c.msm_ws.p + ws.off_tree2;
-    void* dst = (char*)d_out + j0 * out_sz;
-    e = affine_out ? ops->to_affine(src, dst, (uint32_t)mm, stream) : ops->to_jacobian(src, dst, (uint32_t)mm, stream);
-    if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
+    if (affine_out) {
+      e = ops->to_affine((char*)c.msm_ws.p + ws.off_tree2, dst, (uint32_t)mm, stream);
+      if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
+    }
     rc = arena_release(c.msm_ws, stream);
     if (rc != H2_OK) return rc;
   }

@@ -23,7 +23,8 @@ struct CurveOps {
   hipError_t (*table_build)(const void* d_bases, void* d_table, uint32_t n, const MsmGeom& g, uint32_t* d_bad, hipStream_t s);
   hipError_t (*msm_launch)(const void* d_table, const void* const* per_column_tables, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
                            const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s,
-                           hipEvent_t ev_start, hipEvent_t ev_stop, hipEvent_t ev_tail);
+                           hipEvent_t ev_start, hipEvent_t ev_stop, hipEvent_t ev_tail,
+                           void* d_out_jac /* optional: m Jacobian results, written by the MSM's last kernel */);
   hipError_t (*srs_powers)(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s);
   hipError_t (*fixed_base_mul)(void* d_out_affine, const void* d_scalars, uint32_t n, hipStream_t s);
   hipError_t (*to_jacobian)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);

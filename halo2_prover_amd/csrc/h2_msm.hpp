@@ -37,8 +37,18 @@
 
 namespace h2 {
 
+// tools/microbench_tail.hip times the stages of the tail kernels with the 100 MHz counter; nothing in the library build
+#ifdef H2_TAIL_STAMPS
+__device__ unsigned long long* h2_stamps;
+#define H2_STAMP(slot)                                                                                              \
+  do {                                                                                                              \
+    if (threadIdx.x == 0) h2_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define H2_STAMP(slot)
+#endif
+
 constexpr uint32_t MSM_SIGN = 0x80000000u;
-constexpr uint32_t MSM_TREE_SEG = 64;     // points summed by one wave (16 quads) of the first tree level
 constexpr uint32_t MSM_MAX_WINDOWS = 48;
 constexpr uint32_t MSM_HOT_SPAN = 256;    // keys cut into more pieces than this take the hierarchical path
 constexpr uint32_t MSM_HOT_SEG = 128;     // pieces summed by one wave of msm_hot_reduce_kernel
@@ -390,6 +400,16 @@ __device__ __forceinline__ Xyzz29<CV> xyzz_shfl_down(const Xyzz29<CV>& p, uint32
   return r;
 }
 
+// One level of a shuffle tree over quads: the lanes below `d` (of a group whose lane index is `lane`) add the point held
+// `d` lanes further up.  The other lanes keep their value: their partner lies outside the group (a lane past the end of
+// the wave reads ITSELF, and adding a point to itself sends the whole wave through the doubling path as well -- 6.2 us
+// per level instead of 3.6, measured with tools/microbench_tail.hip).
+template <class CV>
+__device__ __forceinline__ Xyzz29<CV> xyzz_fold_down(const Xyzz29<CV>& a, uint32_t d, uint32_t lane) {
+  const Xyzz29<CV> o = xyzz_shfl_down(a, d);
+  return lane < d ? xyzz29_add_quad(a, o) : a;
+}
+
 // piece p of a key whose list starts at entry s and spans chunks j0..: p = 0 is chunk j0's tail (or head when the
 // list starts exactly at the chunk), p >= 1 is the head of chunk j0 + p
 template <class CV>
@@ -470,7 +490,7 @@ msm_hot_reduce_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T
     const uint32_t lo = q * MSM_HOT_SEG, hi = min(span, lo + MSM_HOT_SEG);
     Xyzz29<CV> a = Xyzz29<CV>::identity();
     for (uint32_t p = lo + quad; p < hi; p += 16) a = xyzz29_add_quad(a, msm_piece<CV>(head, tail, s, j0, T, p));
-    for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz29_add_quad(a, xyzz_shfl_down(a, d));
+    for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_fold_down(a, d, threadIdx.x);
     if (threadIdx.x == 0) xyzz29_store<CV>(hot_part + XYZZ29_WORDS * (size_t)(hot_slot[key] + q), a);
   }
 }
@@ -509,53 +529,122 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host
       }
     }
   }
-  for (uint32_t d = G >> 1; d >= 4; d >>= 1) x = xyzz29_add_quad(x, xyzz_shfl_down(x, d));
+  for (uint32_t d = G >> 1; d >= 4; d >>= 1) x = xyzz_fold_down(x, d, lane);
   if (live && lane == 0) xyzz29_store<CV>(xsum + XYZZ29_WORDS * key, x);
 }
 
-// Bucket weights: weighted[key] = (bucket + 1) * xsum[key], one QUAD per key (MSB-first double-and-add with the
-// 4-lanes-per-point arithmetic: a doubling is 3 multiplication levels deep, an addition 4).
-// (A signed non-adjacent form of the multiplier was measured: slower.  A wave holds 16 quads with 16 different
-// multipliers, so some quad adds at nearly every bit whatever the recoding, and the +x / -x cases then run one after
-// the other.)
-template <class CV>
-__global__ void __launch_bounds__(256)
-msm_weight_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ weighted, size_t K, uint32_t bucket_mask) {
-  __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
-  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t key = gt >> 2;
-  if (key >= K) return;                       // whole quads leave together (K * 4 threads are launched)
-  Xyzz29<CV> x = xyzz29_load<CV>(xsum + XYZZ29_WORDS * key);
-  Xyzz29<CV> r = Xyzz29<CV>::identity();
-  if (!x.is_identity()) {
-    const uint32_t k = ((uint32_t)key & bucket_mask) + 1;
-    const int top = 31 - __clz(k);
-    r = x;
-    for (int bit = top - 1; bit >= 0; bit--) {
-      r = xyzz29_double_quad(r);
-      if ((k >> bit) & 1) r = xyzz29_add_quad(r, x);
-    }
-  }
-  if ((gt & 3) == 0) xyzz29_store<CV>(weighted + XYZZ29_WORDS * key, r);
-}
-
-// ---- tree sum: out[col][blockIdx.x] = sum of the `seg` points in[col][blockIdx.x*seg ...] -------------
-// One 64-lane wave per block (so every wave gets a SIMD of its own on a different CU) = 16 quads with 4 lanes per
-// point: quad g folds points g, g+16, ..., then a 4-level shuffle tree across the quads.  Level 1 uses seg = 64,
-// level 2 sums the B/64 partials of a column in one wave.
+// ---- bucket weights without multiplying every bucket --------------------------------------------------------------
+// A column's result is sum_b (b + 1) * x_b over its B = 2^log_b buckets.  Write b = hi * 2^lb + lo and let
+//     R_hi = sum_lo x_b   (a row of 2^lb consecutive buckets),      C_lo = sum_hi x_b   (a column, stride 2^lb);
+// then   sum_b (b + 1) x_b  =  2^lb * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo      (sum_lo C_lo = sum_b x_b).
+// So the B buckets only take part in two plain sums each (msm_rowcol_kernel, 2 B additions per column), and the
+// double-and-add multiplications are left for the 2^hb + 2^lb row / column sums, with multipliers of hb resp. lb bits
+// (msm_final_kernel).  Before: one 12-bit double-and-add per bucket (12 doublings + ~6 additions, 75 us per launch at
+// the proof shape -- VALU-bound, 16 384 quads on 1024 SIMDs) and a two-level tree behind it (2 x 42 us).
+//
+// One wave per row or column sum: 16 quads (4 lanes per point, h2_curve_quad.hpp) fold the points quad, quad + 16, ...
+// and a 4-level shuffle tree joins them.
 template <class CV>
 __global__ void __launch_bounds__(64)
-msm_tree_sum_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t count /* per column */,
-                    uint32_t seg, uint32_t out_per_col) {
+msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, uint32_t* __restrict__ done,
+                  uint32_t log_b, uint32_t lb) {
   __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   const uint32_t col = blockIdx.y;
-  const uint32_t base = blockIdx.x * seg;
-  const uint32_t end = min(base + seg, count);
-  Xyzz29<CV> a = Xyzz29<CV>::identity();
-  for (uint32_t idx = base + (threadIdx.x >> 2); idx < end; idx += 16)
-    a = xyzz29_add_quad(a, xyzz29_load<CV>(in + XYZZ29_WORDS * ((size_t)col * count + idx)));
-  for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz29_add_quad(a, xyzz_shfl_down(a, d));
-  if (threadIdx.x == 0) xyzz29_store<CV>(out + XYZZ29_WORDS * ((size_t)col * out_per_col + blockIdx.x), a);
+  if (blockIdx.x == 0 && threadIdx.x == 0) done[col] = 0;       // msm_final_kernel's arrival counter
+  const uint32_t rows = 1u << (log_b - lb), cols = 1u << lb;
+  const bool is_row = blockIdx.x < rows;
+  const uint32_t first = is_row ? blockIdx.x * cols : blockIdx.x - rows;
+  const uint32_t stride = is_row ? 1u : cols, len = is_row ? cols : rows;
+  const uint32_t* base = xsum + XYZZ29_WORDS * ((size_t)col << log_b);
+  const uint32_t quad = threadIdx.x >> 2;
+  // the first point is taken as it is: an addition onto the identity costs as much as any other
+  Xyzz29<CV> a = quad < len ? xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + quad * stride)) : Xyzz29<CV>::identity();
+  for (uint32_t j = quad + 16; j < len; j += 16)
+    a = xyzz29_add_quad(a, xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + j * stride)));
+  for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_fold_down(a, d, threadIdx.x);
+  if (threadIdx.x == 0) xyzz29_store<CV>(rc + XYZZ29_WORDS * ((size_t)col * (rows + cols) + blockIdx.x), a);
+}
+
+// k * x by MSB-first double-and-add on a quad (k > 0; the quads of a wave run their own bit patterns one after the
+// other where they differ, so a wave costs about bits x (double + add))
+template <class CV>
+__device__ __forceinline__ Xyzz29<CV> xyzz29_mul_small_quad(const Xyzz29<CV>& x, uint32_t k) {
+  Xyzz29<CV> r = x;
+  for (int bit = 30 - __clz(k); bit >= 0; bit--) {
+    r = xyzz29_double_quad(r);
+    if ((k >> bit) & 1) r = xyzz29_add_quad(r, x);
+  }
+  return r;
+}
+
+// Eight one-wave blocks per column, each on a SIMD of its own (two waves sharing a SIMD run these chains at half
+// speed: the 4-lanes-per-point arithmetic keeps a SIMD's issue port busy with ONE wave): blocks 0-3 weigh the row
+// sums (hi * R_hi), blocks 4-7 the column sums ((lo + 1) * C_lo), a shuffle tree joins the wave's 16 quads, and the
+// block that arrives last (a counter per column, zeroed by msm_rowcol_kernel) adds the eight partials, doubles the
+// row family lb times and writes the column's MSM: XYZZ on the working form to out[col] and, when out_jac is given,
+// the Jacobian point in the API's form.
+constexpr uint32_t MSM_FINAL_BLOCKS = 8;
+template <class CV>
+__global__ void __launch_bounds__(64)
+msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x 8 points */, uint32_t* done,
+                 uint32_t* __restrict__ out, U128* __restrict__ out_jac, uint32_t log_b, uint32_t lb) {
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t col = blockIdx.y;
+  const uint32_t rows = 1u << (log_b - lb), cols = 1u << lb;
+  const uint32_t fam = blockIdx.x >> 2;
+  const uint32_t quad = threadIdx.x >> 2;
+  const uint32_t cnt = fam ? cols : rows;
+  const uint32_t* src = rc + XYZZ29_WORDS * ((size_t)col * (rows + cols) + (fam ? rows : 0));
+  Xyzz29<CV> acc = Xyzz29<CV>::identity();
+  bool have = false;
+  H2_STAMP(0);
+  for (uint32_t i = (blockIdx.x & 3u) * 16 + quad; i < cnt; i += 64) {
+    const Xyzz29<CV> x = xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)i);
+    const uint32_t k = fam ? i + 1 : i;
+    Xyzz29<CV> r = Xyzz29<CV>::identity();
+    if (k != 0 && !x.is_identity()) r = xyzz29_mul_small_quad(x, k);
+    acc = have ? xyzz29_add_quad(acc, r) : r;
+    have = true;
+  }
+  H2_STAMP(1);
+  for (uint32_t d = 32; d >= 4; d >>= 1) acc = xyzz_fold_down(acc, d, threadIdx.x);
+  H2_STAMP(2);
+  uint32_t* mine = part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + blockIdx.x);
+  uint32_t arrived = 0;
+  if (threadIdx.x == 0) {
+    xyzz29_store<CV>(mine, acc);
+    __threadfence();                                   // the partial is visible device-wide before the count
+    arrived = atomicAdd(done + col, 1u);
+  }
+  arrived = __shfl(arrived, 0, 64);
+  H2_STAMP(3);
+  if (arrived != MSM_FINAL_BLOCKS - 1) return;
+  __threadfence();
+  // quads 0-3: row-family partials, quads 4-7: column-family partials
+  Xyzz29<CV> p = Xyzz29<CV>::identity();
+  if (quad < MSM_FINAL_BLOCKS) p = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + quad));
+  H2_STAMP(4);
+  // quads 0-3 and 4-7 are two groups of 16 lanes: fold each down to its first quad
+  p = xyzz_fold_down(p, 8, threadIdx.x & 15u);
+  p = xyzz_fold_down(p, 4, threadIdx.x & 15u);
+  H2_STAMP(5);
+  const Xyzz29<CV> lo = xyzz_shfl_down(p, 16);          // quad 0 receives quad 4's sum
+  for (uint32_t i = 0; i < lb; i++) p = xyzz29_double_quad(p);
+  H2_STAMP(6);
+  p = xyzz29_add_quad(p, lo);
+  H2_STAMP(7);
+  if (threadIdx.x == 0) {
+    xyzz29_store<CV>(out + XYZZ29_WORDS * (size_t)col, p);
+    if (out_jac) {
+      using B = typename CV::Base;
+      Fe<B> x, y, z;
+      xyzz_to_jacobian(xyzz29_to_api(p), x, y, z);
+      fe_store<B>(out_jac + 6 * (size_t)col, x);
+      fe_store<B>(out_jac + 6 * (size_t)col + 2, y);
+      fe_store<B>(out_jac + 6 * (size_t)col + 4, z);
+    }
+  }
+  H2_STAMP(8);
 }
 
 constexpr uint32_t MSM_MAX_MULTI = 16;    // columns of a launch that may each bring their own bases
@@ -693,9 +782,10 @@ struct MsmWorkspace {
   size_t nchunks;       // ceil(E / T)
   uint32_t log_g;       // lanes per key in the fix-up kernel = 2^log_g
   uint32_t tile;        // scalars per block in the digits / scatter kernels
-  uint32_t lvl1;        // partials per column after the first tree level
+  uint32_t lb;          // low bits of a bucket index in the row / column split of the weights (msm_rowcol_kernel)
+  uint32_t rc;          // row + column sums per column = 2^(log_b - lb) + 2^lb
   size_t off_counts, off_offsets, off_tile_base, off_blocksums, off_ref, off_key, off_misc, off_bsum,
-      off_head, off_tail, off_xsum, off_weighted, off_tree1, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
+      off_head, off_tail, off_xsum, off_rc, off_part, off_done, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
   uint32_t max_tasks;
 };
 inline size_t h2_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -743,10 +833,11 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   const size_t dense = (size_t)2 * g.B / g.W;
   if (tile < dense) tile = dense;
   if (tile < 256) tile = 256;
-  tile *= 2;   // measured with 1024-thread blocks (MSM_SORT_THREADS): longer runs per (tile, bucket), fewer sector writes
+  tile *= (size_t)tune_int("H2_TUNE_TILE_MUL", 2);   // measured with 1024-thread blocks (MSM_SORT_THREADS): longer runs per (tile, bucket), fewer sector writes
   if (tile > n) tile = n;
   ws.tile = (uint32_t)tile;
-  ws.lvl1 = (g.B + MSM_TREE_SEG - 1) / MSM_TREE_SEG;
+  ws.lb = (g.c - 1) / 2;
+  ws.rc = (1u << (g.c - 1 - ws.lb)) + (1u << ws.lb);
   size_t o = 0;
   ws.off_misc = o; o += 256;                                      // misc[0] = hot task counter; zeroed with counts
   ws.off_counts = o; o = h2_align256(o + ws.K * 4);
@@ -759,8 +850,9 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_head = o; o = h2_align256(o + ws.nchunks * (XYZZ29_WORDS * 4));
   ws.off_tail = o; o = h2_align256(o + ws.nchunks * (XYZZ29_WORDS * 4));
   ws.off_xsum = o; o = h2_align256(o + ws.K * (XYZZ29_WORDS * 4));
-  ws.off_weighted = o; o = h2_align256(o + ws.K * (XYZZ29_WORDS * 4));
-  ws.off_tree1 = o; o = h2_align256(o + m * ws.lvl1 * (XYZZ29_WORDS * 4));
+  ws.off_rc = o; o = h2_align256(o + m * ws.rc * (XYZZ29_WORDS * 4));
+  ws.off_part = o; o = h2_align256(o + m * MSM_FINAL_BLOCKS * (XYZZ29_WORDS * 4));
+  ws.off_done = o; o = h2_align256(o + m * 4);
   ws.off_tree2 = o; o = h2_align256(o + m * (XYZZ29_WORDS * 4));
   // hot keys: a key with span > MSM_HOT_SPAN emits ceil(span / SEG) <= span / SEG + 1 <= span / SEG + span / SPAN
   // tasks, and the spans of all keys add up to at most nchunks + K_hot <= nchunks * (1 + 1 / SPAN)
@@ -790,7 +882,8 @@ template <class CV>
 inline hipError_t msm_launch(const U128* table, const U128* const* per_column /* host array of m tables, or null */,
                              uint32_t n_bases, const U128* d_scalars, size_t n, size_t col_stride,
                              size_t m, const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
-                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, hipEvent_t ev_tail = nullptr) {
+                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, hipEvent_t ev_tail = nullptr,
+                             U128* d_out_jac = nullptr /* m Jacobian points in the API's form, written by the last kernel */) {
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
   uint32_t* tile_base = (uint32_t*)(ws_base + ws.off_tile_base);
@@ -802,8 +895,7 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   uint32_t* head = (uint32_t*)(ws_base + ws.off_head);
   uint32_t* tail = (uint32_t*)(ws_base + ws.off_tail);
   uint32_t* xsum = (uint32_t*)(ws_base + ws.off_xsum);
-  uint32_t* weighted = (uint32_t*)(ws_base + ws.off_weighted);
-  uint32_t* tree1 = (uint32_t*)(ws_base + ws.off_tree1);
+  uint32_t* rc = (uint32_t*)(ws_base + ws.off_rc);
   uint32_t* tree2 = (uint32_t*)(ws_base + ws.off_tree2);
   uint32_t* hot_slot = (uint32_t*)(ws_base + ws.off_hot_slot);
   uint32_t* hot_tasks = (uint32_t*)(ws_base + ws.off_hot_tasks);
@@ -851,17 +943,11 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   const size_t fix_threads = ws.K << ws.log_g;
   hipLaunchKernelGGL(msm_fixup_kernel<CV>, dim3((unsigned)((fix_threads + 255) / 256)), dim3(256), 0, stream, offsets,
                      ws.K, ws.T, ws.log_g, bsum, head, tail, hot_slot, hot_part, xsum);
-  hipLaunchKernelGGL(msm_weight_kernel<CV>, dim3((unsigned)((ws.K * 4 + 255) / 256)), dim3(256), 0, stream, xsum,
-                     weighted, ws.K, g.B - 1);
-  if (ws.lvl1 == 1) {
-    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(64), 0, stream, weighted, tree2, g.B, g.B,
-                       1u);
-  } else {
-    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(ws.lvl1, (unsigned)m), dim3(64), 0, stream, weighted, tree1, g.B,
-                       MSM_TREE_SEG, ws.lvl1);
-    hipLaunchKernelGGL(msm_tree_sum_kernel<CV>, dim3(1, (unsigned)m), dim3(64), 0, stream, tree1, tree2, ws.lvl1,
-                       ws.lvl1, 1u);
-  }
+  uint32_t* part = (uint32_t*)(ws_base + ws.off_part);
+  uint32_t* done = (uint32_t*)(ws_base + ws.off_done);
+  hipLaunchKernelGGL(msm_rowcol_kernel<CV>, dim3(ws.rc, (unsigned)m), dim3(64), 0, stream, xsum, rc, done, g.c - 1, ws.lb);
+  hipLaunchKernelGGL(msm_final_kernel<CV>, dim3(MSM_FINAL_BLOCKS, (unsigned)m), dim3(64), 0, stream, rc, part, done, tree2,
+                     d_out_jac, g.c - 1, ws.lb);
   return hipGetLastError();
 }
 

@@ -8,7 +8,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#include "../halo2_prover_amd/csrc/h2_curve_quad.hpp"
+#define H2_TAIL_STAMPS 1
+#include "../halo2_prover_amd/csrc/h2_msm.hpp"
 
 using namespace h2;
 using CV = PALLAS_CURVE;
@@ -53,6 +54,50 @@ __global__ void __launch_bounds__(256) k_lane_mixed(uint32_t* out, int iters) {
   xyzz29_store<CV>(out + XYZZ29_WORDS * (size_t)t, a);
 }
 
+__global__ void k_fill(uint32_t* pts, uint32_t count) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) xyzz29_store<CV>(pts + XYZZ29_WORDS * (size_t)t, seed_point(t));
+}
+
+// the row / column tail of the MSM on synthetic bucket sums, stage by stage (100 MHz stamps from the kernels)
+static void tail_stages() {
+  const uint32_t m = 4, log_b = 12, lb = 6, B = 1u << log_b, rcn = (1u << (log_b - lb)) + (1u << lb);
+  uint32_t *xsum, *rc, *part, *done, *out;
+  U128* jac;
+  unsigned long long* stamps;
+  hipMalloc(&xsum, (size_t)m * B * XYZZ29_WORDS * 4);
+  hipMalloc(&rc, (size_t)m * rcn * XYZZ29_WORDS * 4);
+  hipMalloc(&part, (size_t)m * MSM_FINAL_BLOCKS * XYZZ29_WORDS * 4);
+  hipMalloc(&done, m * 4);
+  hipMalloc(&out, m * XYZZ29_WORDS * 4);
+  hipMalloc(&jac, m * 96);
+  hipMalloc(&stamps, 16 * 8 * 1024);
+  hipMemset(stamps, 0, 16 * 8 * 1024);
+  hipMemcpyToSymbol(HIP_SYMBOL(h2_stamps), &stamps, sizeof(stamps));
+  hipLaunchKernelGGL(k_fill, dim3((m * B + 255) / 256), dim3(256), 0, 0, xsum, m * B);
+  std::vector<unsigned long long> h(16 * MSM_FINAL_BLOCKS * m);
+  for (int rep = 0; rep < 3; rep++) {
+    hipLaunchKernelGGL(msm_rowcol_kernel<CV>, dim3(rcn, m), dim3(64), 0, 0, xsum, rc, done, log_b, lb);
+    hipDeviceSynchronize();
+    hipMemset(stamps, 0, 16 * 8 * 1024);
+    hipLaunchKernelGGL(msm_final_kernel<CV>, dim3(MSM_FINAL_BLOCKS, m), dim3(64), 0, 0, rc, part, done, out, jac, log_b, lb);
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (size_t b = 0; b < MSM_FINAL_BLOCKS * m; b++) if (h[b * 16] && h[b * 16] < t0) t0 = h[b * 16];
+    printf("  msm_final_kernel stages, run %d (us since the first wave started; block = family*4 + part, column 0):\n", rep);
+    for (uint32_t b = 0; b < MSM_FINAL_BLOCKS; b++) {
+      printf("    block %u:", b);
+      for (int i = 0; i < 9; i++) {
+        if (h[b * 16 + i]) printf(" %7.2f", (double)(h[b * 16 + i] - t0) / 100.0);
+        else printf("       -");
+      }
+      printf("\n");
+    }
+  }
+  printf("  stamps: 0 start, 1 weights done, 2 wave tree done, 3 counted, 4 partials loaded, 5 joined, 6 doubled, 7 added, 8 stored\n");
+}
+
 template <class F>
 double time_kernel(F launch) {
   hipEvent_t e0, e1;
@@ -68,7 +113,9 @@ double time_kernel(F launch) {
   return best;
 }
 
+#include <vector>
 int main() {
+  tail_stages();
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   const int cus = prop.multiProcessorCount;
