@@ -147,19 +147,51 @@ H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w,
   return raw;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by linear block id, and every XCD has an L2 of its own.  The sort's
+// two kernels therefore give XCD x a CONTIGUOUS range of (column, tile) pairs and a counter set of its own:
+//     group x = blockIdx.x % 8,   virtual id v = x * per + blockIdx.x / 8   (per = ceil(total / 8)),
+//     (column, tile) = (v / tiles, v % tiles).
+// A bucket's list is then laid out group by group (group x starts behind the counts of the groups below it), so the
+// stores that land in one 64-byte sector nearly all come from one XCD.  Measured (Poseidon k = 16 shape): the scatter
+// kernel 65 -> 52 us.  WRITE_SIZE did NOT fall (162 -> 152 MB for 21 MB of entries): on this chip every store
+// instruction's bytes leave the L2 as they are written (MI355X_MICROARCH.md, stores of each flavour), so a scattered
+// 4-byte store is one fabric write whatever the L2 holds -- only wider runs per store instruction would change that.
+// If the hardware mapped blocks differently only the locality would suffer: both kernels compute the same (group, tile).
+constexpr uint32_t MSM_XCDS = 8;
+struct MsmTileId {
+  uint32_t group, col, tile;
+  bool live;
+};
+__device__ __forceinline__ MsmTileId msm_tile_id(uint32_t tiles, uint32_t m) {
+  const uint32_t total = tiles * m, per = (total + MSM_XCDS - 1) / MSM_XCDS;
+  MsmTileId t;
+  t.group = blockIdx.x % MSM_XCDS;
+  const uint32_t v = t.group * per + blockIdx.x / MSM_XCDS;
+  t.live = blockIdx.x / MSM_XCDS < per && v < total;
+  t.col = v / tiles;
+  t.tile = v % tiles;
+  return t;
+}
+inline uint32_t msm_tile_grid(uint32_t tiles, uint32_t m) {
+  return (tiles * m + MSM_XCDS - 1) / MSM_XCDS * MSM_XCDS;
+}
+
 // Count pass: every scalar's signed digits (0 or |d| | sign<<31) go into an LDS histogram of the tile;
-// counts[col*B + |d|-1] += the tile's count with one RETURNING global atomic per non-empty bucket, whose result --
-// where this tile's entries start inside the bucket's list -- is kept in tile_base.  grid = (tiles, m), LDS B*4.
+// gcounts[group][col*B + |d|-1] += the tile's count with one RETURNING global atomic per non-empty bucket, whose
+// result -- where this tile's entries start inside the group's part of the bucket's list -- is kept in tile_base.
+// grid = msm_tile_grid(tiles, m), LDS B*4.
 template <class CV>
 __global__ void __launch_bounds__(1024)
-msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base,
-                  uint32_t n, size_t col_stride /* elements */, uint32_t tile, MsmGeom g) {
+msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ gcounts, uint32_t* __restrict__ tile_base,
+                  uint32_t n, size_t col_stride /* elements */, uint32_t tile, uint32_t tiles, uint32_t m, MsmGeom g) {
   using S = typename CV::Scalar;
   extern __shared__ uint32_t hist[];
-  const uint32_t col = blockIdx.y;
+  const MsmTileId id = msm_tile_id(tiles, m);
+  if (!id.live) return;
+  const uint32_t col = id.col;
   for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  const uint32_t lo = blockIdx.x * tile, hi = min(lo + tile, n);
+  const uint32_t lo = id.tile * tile, hi = min(lo + tile, n);
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
     uint32_t carry = 0;
@@ -169,12 +201,22 @@ msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ count
     }
   }
   __syncthreads();
-  // the value the atomic returns is where this tile's entries start inside the bucket's list: kept for the scatter
-  uint32_t* tb = tile_base + ((size_t)col * gridDim.x + blockIdx.x) * g.B;
+  // the value the atomic returns is where this tile's entries start inside the group's run: kept for the scatter
+  uint32_t* tb = tile_base + ((size_t)col * tiles + id.tile) * g.B;
+  uint32_t* gc = gcounts + (size_t)id.group * ((size_t)m * g.B) + (size_t)col * g.B;
   for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) {
     const uint32_t h = hist[b];
-    tb[b] = h ? atomicAdd(&counts[(size_t)col * g.B + b], h) : 0u;
+    tb[b] = h ? atomicAdd(&gc[b], h) : 0u;
   }
+}
+
+// counts[key] = the key's entries over all groups (the multi-kernel scan's input)
+static __global__ void __launch_bounds__(256) msm_group_fold_kernel(const uint32_t* __restrict__ gcounts, uint32_t* __restrict__ counts, size_t K) {
+  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= K) return;
+  uint32_t run = 0;
+  for (uint32_t x = 0; x < MSM_XCDS; x++) run += gcounts[x * K + key];
+  counts[key] = run;
 }
 
 // ---- exclusive scan over K counts (three small kernels) -------------------------------------
@@ -227,10 +269,16 @@ scan_blocksums_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out) {
 // 21 us against 14 us for the three launches below.)
 constexpr uint32_t SCAN_LDS_MAX = 32 * 1024;
 static __global__ void __launch_bounds__(1024)
-scan_lds_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ offsets, uint32_t K, uint32_t per) {
+scan_lds_kernel(const uint32_t* __restrict__ gcounts, uint32_t* __restrict__ offsets, uint32_t K, uint32_t per) {
   extern __shared__ uint32_t buf[];            // K words (+1 spare per 32 to spread banks is not needed: per is odd)
   __shared__ uint32_t wave_sum[16];
-  for (uint32_t i = threadIdx.x; i < K; i += 1024) buf[i] = in[i];
+  // a key's count is the sum over the groups (msm_group_fold_kernel's work, without its launch)
+  for (uint32_t i = threadIdx.x; i < K; i += 1024) {
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < MSM_XCDS; x++) run += gcounts[(size_t)x * K + i];
+    buf[i] = run;
+  }
   __syncthreads();
   const uint32_t lo = threadIdx.x * per, hi = min(K, lo + per);
   uint32_t s = 0;
@@ -294,16 +342,26 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
 template <class CV>
 __global__ void __launch_bounds__(1024)
 msm_scatter_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict__ offsets,
-                   const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ sorted_ref, uint32_t n,
-                   size_t col_stride /* elements */, uint32_t n_bases, uint32_t tile, MsmGeom g) {
+                   const uint32_t* __restrict__ gcounts, const uint32_t* __restrict__ tile_base,
+                   uint32_t* __restrict__ sorted_ref, uint32_t n, size_t col_stride /* elements */, uint32_t n_bases,
+                   uint32_t tile, uint32_t tiles, uint32_t m, MsmGeom g) {
   using S = typename CV::Scalar;
   extern __shared__ uint32_t hist[];
-  const uint32_t col = blockIdx.y;
-  // LDS cursors: list start + this tile's base inside the list (handed out by the digits kernel's atomics)
-  const uint32_t* tb = tile_base + ((size_t)col * gridDim.x + blockIdx.x) * g.B;
-  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) hist[b] = offsets[(size_t)col * g.B + b] + tb[b];
+  const MsmTileId id = msm_tile_id(tiles, m);
+  if (!id.live) return;
+  const uint32_t col = id.col;
+  // LDS cursors: list start + the group's start inside the list + this tile's base inside the group's run (handed out
+  // by the digits kernel's atomics)
+  const uint32_t* tb = tile_base + ((size_t)col * tiles + id.tile) * g.B;
+  const uint32_t* gc = gcounts + (size_t)col * g.B;
+  const size_t K = (size_t)m * g.B;
+  for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) {
+    uint32_t at = offsets[(size_t)col * g.B + b] + tb[b];
+    for (uint32_t x = 0; x < id.group; x++) at += gc[x * K + b];     // the groups below this one come first in the list
+    hist[b] = at;
+  }
   __syncthreads();
-  const uint32_t lo = blockIdx.x * tile, hi = min(lo + tile, n);
+  const uint32_t lo = id.tile * tile, hi = min(lo + tile, n);
   // the digits are recomputed rather than stored by the first kernel: 32 bytes of scalar instead of 4 W bytes of digits
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
@@ -784,7 +842,7 @@ struct MsmWorkspace {
   uint32_t tile;        // scalars per block in the digits / scatter kernels
   uint32_t lb;          // low bits of a bucket index in the row / column split of the weights (msm_rowcol_kernel)
   uint32_t rc;          // row + column sums per column = 2^(log_b - lb) + 2^lb
-  size_t off_counts, off_offsets, off_tile_base, off_blocksums, off_ref, off_key, off_misc, off_bsum,
+  size_t off_counts, off_gcounts, off_offsets, off_tile_base, off_blocksums, off_ref, off_key, off_misc, off_bsum,
       off_head, off_tail, off_xsum, off_rc, off_part, off_done, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
   uint32_t max_tasks;
 };
@@ -840,7 +898,8 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.rc = (1u << (g.c - 1 - ws.lb)) + (1u << ws.lb);
   size_t o = 0;
   ws.off_misc = o; o += 256;                                      // misc[0] = hot task counter; zeroed with counts
-  ws.off_counts = o; o = h2_align256(o + ws.K * 4);
+  ws.off_counts = o; o = h2_align256(o + ws.K * 4);                // per-key totals (only the multi-kernel scan reads them)
+  ws.off_gcounts = o; o = h2_align256(o + MSM_XCDS * ws.K * 4);    // per XCD group; zeroed with misc and counts
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
   ws.off_tile_base = o; o = h2_align256(o + ((n + ws.tile - 1) / ws.tile) * ws.K * 4);   // tiles x (m * B) words
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
@@ -885,6 +944,7 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, hipEvent_t ev_tail = nullptr,
                              U128* d_out_jac = nullptr /* m Jacobian points in the API's form, written by the last kernel */) {
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
+  uint32_t* gcounts = (uint32_t*)(ws_base + ws.off_gcounts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
   uint32_t* tile_base = (uint32_t*)(ws_base + ws.off_tile_base);
   uint32_t* blocksums = (uint32_t*)(ws_base + ws.off_blocksums);
@@ -904,23 +964,25 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   // one memset: misc (256 B) sits directly before counts.  Nothing else needs clearing: every slot of bucket_sum /
   // head / tail that a later kernel reads has been written by the accumulate kernel (the fix-up decides from
   // `offsets` which slots exist).
-  if ((e = hipMemsetAsync(misc, 0, 256 + ws.K * 4, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(misc, 0, ws.off_gcounts + MSM_XCDS * ws.K * 4 - ws.off_misc, stream)) != hipSuccess) return e;
   const size_t lds = (size_t)g.B * 4;     // dynamic LDS limits were raised once per device by msm_kernel_setup
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
-  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, counts,
-                     tile_base, (uint32_t)n, col_stride, ws.tile, g);
+  const uint32_t sort_grid = msm_tile_grid(tiles, (uint32_t)m);
+  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, gcounts,
+                     tile_base, (uint32_t)n, col_stride, ws.tile, tiles, (uint32_t)m, g);
   if (ws.K <= SCAN_LDS_MAX) {
     uint32_t per = (uint32_t)((ws.K + 1023) / 1024);
     per |= 1u;                                 // odd stride: the per-thread LDS walks do not collide on banks
-    hipLaunchKernelGGL(scan_lds_kernel, dim3(1), dim3(1024), ws.K * 4, stream, counts, offsets, (uint32_t)ws.K, per);
+    hipLaunchKernelGGL(scan_lds_kernel, dim3(1), dim3(1024), ws.K * 4, stream, gcounts, offsets, (uint32_t)ws.K, per);
   } else {
+  hipLaunchKernelGGL(msm_group_fold_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, gcounts, counts, ws.K);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      ws.K);
   }
-  hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(tiles, (unsigned)m), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
-                     tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, g);
+  hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
+                     gcounts, tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles, (uint32_t)m, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
   const U128** d_tables = nullptr;
