@@ -582,8 +582,15 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host
         const uint32_t nseg = (j1 - j0 + 1 + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
         const uint32_t* part = hot_part + XYZZ29_WORDS * (size_t)hot_slot[key];
         for (uint32_t q = quad; q < nseg; q += nquad) x = xyzz29_add_quad(x, xyzz29_load<CV>(part + XYZZ29_WORDS * (size_t)q));
-      } else {
-        for (uint32_t p = quad; p <= j1 - j0; p += nquad) x = xyzz29_add_quad(x, msm_piece<CV>(head, tail, s, j0, T, p));
+      } else if (quad <= j1 - j0) {
+        // the next piece is on its way while the current one is added (a piece is 144 bytes from HBM: ~1.5 us exposed
+        // per addition otherwise, the chain has nothing else to do)
+        Xyzz29<CV> nxt = msm_piece<CV>(head, tail, s, j0, T, quad);
+        for (uint32_t p = quad; p <= j1 - j0; p += nquad) {
+          const Xyzz29<CV> cur = nxt;
+          if (p + nquad <= j1 - j0) nxt = msm_piece<CV>(head, tail, s, j0, T, p + nquad);
+          x = xyzz29_add_quad(x, cur);
+        }
       }
     }
   }
@@ -623,84 +630,142 @@ msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, 
   if (threadIdx.x == 0) xyzz29_store<CV>(rc + XYZZ29_WORDS * ((size_t)col * (rows + cols) + blockIdx.x), a);
 }
 
-// k * x by MSB-first double-and-add on a quad (k > 0; the quads of a wave run their own bit patterns one after the
-// other where they differ, so a wave costs about bits x (double + add))
+// word-wise choice among three points by a per-quad digit (0 -> the identity, which is all zeros)
 template <class CV>
-__device__ __forceinline__ Xyzz29<CV> xyzz29_mul_small_quad(const Xyzz29<CV>& x, uint32_t k) {
-  Xyzz29<CV> r = x;
-  for (int bit = 30 - __clz(k); bit >= 0; bit--) {
-    r = xyzz29_double_quad(r);
-    if ((k >> bit) & 1) r = xyzz29_add_quad(r, x);
+__device__ __forceinline__ Xyzz29<CV> xyzz29_pick(uint32_t dig, const Xyzz29<CV>& p1, const Xyzz29<CV>& p2, const Xyzz29<CV>& p3) {
+  const int32_t m1 = -(int32_t)(dig == 1), m2 = -(int32_t)(dig == 2), m3 = -(int32_t)(dig == 3);
+  Xyzz29<CV> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.x.v[i] = (m1 & p1.x.v[i]) | (m2 & p2.x.v[i]) | (m3 & p3.x.v[i]);
+    r.y.v[i] = (m1 & p1.y.v[i]) | (m2 & p2.y.v[i]) | (m3 & p3.y.v[i]);
+    r.zz.v[i] = (m1 & p1.zz.v[i]) | (m2 & p2.zz.v[i]) | (m3 & p3.zz.v[i]);
+    r.zzz.v[i] = (m1 & p1.zzz.v[i]) | (m2 & p2.zzz.v[i]) | (m3 & p3.zzz.v[i]);
   }
   return r;
 }
 
 // Eight one-wave blocks per column, each on a SIMD of its own (two waves sharing a SIMD run these chains at half
-// speed: the 4-lanes-per-point arithmetic keeps a SIMD's issue port busy with ONE wave): blocks 0-3 weigh the row
-// sums (hi * R_hi), blocks 4-7 the column sums ((lo + 1) * C_lo), a shuffle tree joins the wave's 16 quads, and the
-// block that arrives last (a counter per column, zeroed by msm_rowcol_kernel) adds the eight partials, doubles the
-// row family lb times and writes the column's MSM: XYZZ on the working form to out[col] and, when out_jac is given,
-// the Jacobian point in the API's form.
+// speed: the 4-lanes-per-point arithmetic keeps a SIMD's issue port busy with ONE wave).  Blocks 0-3 weigh the row
+// family, blocks 4-7 the column family, 16 items per wave and round:
+//     row family     item 0 = C_(cols-1) with multiplier 1 (its own multiplier 2^lb = 2^lb * 1 joins the rows, whose
+//                    item 0 would have multiplier 0), item hi = R_hi with multiplier hi            (< 2^hb)
+//     column family  item lo = C_lo with multiplier lo + 1, lo < cols - 1                           (< 2^lb)
+// multiplied two bits at a time (x, 2x, 3x, then per digit two doublings and one addition of the quad's own choice),
+// a shuffle tree over the wave's 16 quads, and the block that arrives last (a counter per column, zeroed by
+// msm_rowcol_kernel) adds the eight partials, doubles the row family lb times and writes the column's MSM: XYZZ on the
+// working form to out[col] and, when out_jac is given, the Jacobian point in the API's form.
+//
+// The whole chain is ONE loop around one doubling and one addition (a little program counter decides what each step
+// does): written as straight-line code the kernel was 180 KB -- every inlined addition is ~24 KB -- and each copy ran
+// exactly once, from a cold instruction cache (4.9 us against 3.6 us for an addition; tools/microbench_tail.hip).
 constexpr uint32_t MSM_FINAL_BLOCKS = 8;
 template <class CV>
 __global__ void __launch_bounds__(64)
 msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x 8 points */, uint32_t* done,
                  uint32_t* __restrict__ out, U128* __restrict__ out_jac, uint32_t log_b, uint32_t lb) {
   __builtin_amdgcn_s_setprio(3);
+  using P = Xyzz29<CV>;
   const uint32_t col = blockIdx.y;
-  const uint32_t rows = 1u << (log_b - lb), cols = 1u << lb;
-  const uint32_t fam = blockIdx.x >> 2;
-  const uint32_t quad = threadIdx.x >> 2;
-  const uint32_t cnt = fam ? cols : rows;
-  const uint32_t* src = rc + XYZZ29_WORDS * ((size_t)col * (rows + cols) + (fam ? rows : 0));
-  Xyzz29<CV> acc = Xyzz29<CV>::identity();
-  bool have = false;
+  const uint32_t hb = log_b - lb, rows = 1u << hb, cols = 1u << lb;
+  const uint32_t fam = blockIdx.x >> 2, lane = threadIdx.x, quad = threadIdx.x >> 2;
+  const uint32_t cnt = fam ? cols - 1 : rows;
+  const uint32_t ndig = ((fam ? lb : hb) + 1) >> 1;              // base-4 digits of the family's multipliers
+  const uint32_t* src = rc + XYZZ29_WORDS * ((size_t)col * (rows + cols));
+  const uint32_t first = (blockIdx.x & 3u) * 16;
+  const uint32_t n_items = first < cnt ? (cnt - first + 63) / 64 : 0;   // the same for the whole wave
+  const uint32_t per_item = 3 * ndig;                            // double, add x, (double, double, add)*, add acc
+  const uint32_t n_weigh = n_items * per_item, n_tree = n_weigh + 4, n_all = n_tree + 3 + lb;
+  P r = P::identity(), x = P::identity(), x2 = P::identity(), x3 = P::identity();
+  P acc = P::identity(), keep = P::identity();
+  uint32_t k = 0;
   H2_STAMP(0);
-  for (uint32_t i = (blockIdx.x & 3u) * 16 + quad; i < cnt; i += 64) {
-    const Xyzz29<CV> x = xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)i);
-    const uint32_t k = fam ? i + 1 : i;
-    Xyzz29<CV> r = Xyzz29<CV>::identity();
-    if (k != 0 && !x.is_identity()) r = xyzz29_mul_small_quad(x, k);
-    acc = have ? xyzz29_add_quad(acc, r) : r;
-    have = true;
-  }
-  H2_STAMP(1);
-  for (uint32_t d = 32; d >= 4; d >>= 1) acc = xyzz_fold_down(acc, d, threadIdx.x);
-  H2_STAMP(2);
-  uint32_t* mine = part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + blockIdx.x);
-  uint32_t arrived = 0;
-  if (threadIdx.x == 0) {
-    xyzz29_store<CV>(mine, acc);
-    __threadfence();                                   // the partial is visible device-wide before the count
-    arrived = atomicAdd(done + col, 1u);
-  }
-  arrived = __shfl(arrived, 0, 64);
-  H2_STAMP(3);
-  if (arrived != MSM_FINAL_BLOCKS - 1) return;
-  __threadfence();
-  // quads 0-3: row-family partials, quads 4-7: column-family partials
-  Xyzz29<CV> p = Xyzz29<CV>::identity();
-  if (quad < MSM_FINAL_BLOCKS) p = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + quad));
-  H2_STAMP(4);
-  // quads 0-3 and 4-7 are two groups of 16 lanes: fold each down to its first quad
-  p = xyzz_fold_down(p, 8, threadIdx.x & 15u);
-  p = xyzz_fold_down(p, 4, threadIdx.x & 15u);
-  H2_STAMP(5);
-  const Xyzz29<CV> lo = xyzz_shfl_down(p, 16);          // quad 0 receives quad 4's sum
-  for (uint32_t i = 0; i < lb; i++) p = xyzz29_double_quad(p);
-  H2_STAMP(6);
-  p = xyzz29_add_quad(p, lo);
-  H2_STAMP(7);
-  if (threadIdx.x == 0) {
-    xyzz29_store<CV>(out + XYZZ29_WORDS * (size_t)col, p);
-    if (out_jac) {
-      using B = typename CV::Base;
-      Fe<B> x, y, z;
-      xyzz_to_jacobian(xyzz29_to_api(p), x, y, z);
-      fe_store<B>(out_jac + 6 * (size_t)col, x);
-      fe_store<B>(out_jac + 6 * (size_t)col + 2, y);
-      fe_store<B>(out_jac + 6 * (size_t)col + 4, z);
+#pragma nounroll
+  for (uint32_t pc = 0; pc < n_all; pc++) {
+    bool is_double = false, wanted = true;
+    P o = P::identity();
+    uint32_t s = 0, it = 0;
+    if (pc < n_weigh) {
+      it = pc / per_item;
+      s = pc - it * per_item;
+      if (s == 0) {                                              // next item: r = x, then 2x
+        const uint32_t i = first + quad + 64 * it;
+        x = P::identity();
+        k = 0;
+        if (i < cnt) {
+          const uint32_t idx = fam ? rows + i : (i == 0 ? rows + cols - 1 : i);
+          x = xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)idx);
+          k = fam ? i + 1 : (i == 0 ? 1u : i);
+        }
+        r = x;
+        is_double = true;
+      } else if (s == 1) {                                       // 3x
+        o = x;
+      } else if (s == per_item - 1) {                            // onto the items before
+        o = acc;
+        wanted = it > 0;
+      } else {
+        const uint32_t t = s - 2, d = ndig - 2 - t / 3;
+        if (t % 3 < 2) is_double = true;
+        else o = xyzz29_pick((k >> (2 * d)) & 3u, x, x2, x3);
+      }
+    } else if (pc < n_tree) {
+      const uint32_t d = 32u >> (pc - n_weigh);
+      o = xyzz_shfl_down(r, d);
+      wanted = lane < d;
+    } else {
+      const uint32_t c = pc - n_tree;                            // the last block: fold 8, fold 4, lb doublings, + columns
+      if (c < 2) {
+        o = xyzz_shfl_down(r, 8u >> c);
+        wanted = (lane & 15u) < (8u >> c);
+      } else if (c < 2 + lb) {
+        if (c == 2) keep = xyzz_shfl_down(r, 16);                // quad 0 receives quad 4's sum (the column family)
+        is_double = true;
+      } else {
+        o = keep;
+      }
     }
+    if (is_double) r = xyzz29_double_quad(r);
+    else if (wanted) r = xyzz29_add_quad(r, o);
+    if (pc < n_weigh) {
+      if (s == 0) x2 = r;
+      else if (s == 1) {
+        x3 = r;
+        r = xyzz29_pick((k >> (2 * (ndig - 1))) & 3u, x, x2, x3);
+      }
+      if (s == per_item - 1) acc = r;
+    }
+    if (pc + 1 == n_tree) {
+      // this wave's partial is complete: publish it, and only the block that arrives last goes on
+      H2_STAMP(2);
+      uint32_t arrived = 0;
+      if (threadIdx.x == 0) {
+        xyzz29_store<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + blockIdx.x), r);
+        __threadfence();                                 // the partial is visible device-wide before the count
+        arrived = atomicAdd(done + col, 1u);
+      }
+      arrived = __shfl(arrived, 0, 64);
+      H2_STAMP(3);
+      if (arrived != MSM_FINAL_BLOCKS - 1) return;
+      __threadfence();
+      // quads 0-3: row-family partials, quads 4-7: column-family partials
+      r = P::identity();
+      if (quad < MSM_FINAL_BLOCKS) r = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + quad));
+      H2_STAMP(4);
+    }
+  }
+  H2_STAMP(7);
+  if (threadIdx.x == 0) xyzz29_store<CV>(out + XYZZ29_WORDS * (size_t)col, r);
+  if (out_jac && threadIdx.x < 4) {
+    // X zz, Y zzz, zz on lanes 0, 1, 2 at once, each lane converting and storing its own coordinate
+    using F = Fe29<typename CV::Base>;
+    using B = typename CV::Base;
+    const uint32_t q = threadIdx.x & 3u;
+    const F one = fe29_one<CV>();
+    const F prod = fe29_mul(quad_select(q, r.x, r.y, r.zz, r.zz), quad_select(q, r.zz, r.zzz, one, one));
+    Fe<B> v = fe29_to_api(prod);
+    if (r.is_identity()) v = Fe<B>::zero();
+    if (q < 3) fe_store<B>(out_jac + 6 * (size_t)col + 2 * q, v);
   }
   H2_STAMP(8);
 }

@@ -95,7 +95,7 @@ static void tail_stages() {
       printf("\n");
     }
   }
-  printf("  stamps: 0 start, 1 weights done, 2 wave tree done, 3 counted, 4 partials loaded, 5 joined, 6 doubled, 7 added, 8 stored\n");
+  printf("  stamps: 0 start, 2 weights and wave tree done, 3 counted, 4 partials loaded, 7 joined, doubled and added, 8 stored\n");
 }
 
 template <class F>
