@@ -515,8 +515,21 @@ struct ExprProgram {
 
   std::vector<pk::XInstr> code;
   uint32_t nslots = 0;
-  // emit instructions for `root` (every arithmetic node it depends on, in order), slots reused after the last use
+  // emit instructions for `root` (every arithmetic node it depends on, in order), slots reused after the last use.
+  // Order: depth first, the operand that needs more live values first (Sethi-Ullman numbering; shared nodes count as
+  // computed).  A result that the NEXT instruction consumes is handed over in a register (operand kind X_PREV), and a
+  // result with no other use is never stored: a slot costs 32 bytes of LDS per row and the slots of 128 rows decide
+  // how many blocks share a CU (h2_prover_kernels.hpp, expr_kernel).
   void compile(int root) {
+    std::vector<int> need(nodes.size(), -1);
+    std::function<int(int)> su = [&](int id) -> int {
+      if (need[id] >= 0) return need[id];
+      const Node& nd = nodes[id];
+      if (nd.op < 2) return need[id] = 0;
+      const int na = su(nd.a), nb = su(nd.b);
+      return need[id] = std::max(1, na == nb ? na + 1 : std::max(na, nb));
+    };
+    su(root);
     std::vector<int> order;
     std::vector<char> seen(nodes.size(), 0);
     std::function<void(int)> visit = [&](int id) {
@@ -524,28 +537,38 @@ struct ExprProgram {
       seen[id] = 1;
       const Node& nd = nodes[id];
       if (nd.op >= 2) {
-        visit(nd.a);
-        visit(nd.b);
+        if (need[nd.b] > need[nd.a]) {
+          visit(nd.b);
+          visit(nd.a);
+        } else {
+          visit(nd.a);
+          visit(nd.b);
+        }
         order.push_back(id);
       }
     };
     visit(root);
+    if (order.empty()) fail(H2_EINVAL, "empty quotient program");
+    std::vector<int> at(nodes.size(), -1);           // instruction index of a node
+    for (size_t t = 0; t < order.size(); t++) at[order[t]] = (int)t;
     std::vector<int> last_use(nodes.size(), -1);
-    for (size_t t = 0; t < order.size(); t++) {
-      last_use[nodes[order[t]].a] = (int)t;
-      last_use[nodes[order[t]].b] = (int)t;
-    }
-    last_use[root] = (int)order.size();
+    std::vector<char> wants_slot(nodes.size(), 0);   // some use is not the very next instruction
+    for (size_t t = 0; t < order.size(); t++)
+      for (int src : {nodes[order[t]].a, nodes[order[t]].b}) {
+        last_use[src] = (int)t;
+        if (nodes[src].op >= 2 && at[src] + 1 != (int)t) wants_slot[src] = 1;
+      }
     std::vector<int> slot_of(nodes.size(), -1);
     std::vector<uint32_t> free_slots;
-    auto operand = [&](int id) -> uint32_t {
-      const Node& nd = nodes[id];
-      if (nd.op == 0) return pk::X_CONST | (uint32_t)nd.cidx;
-      if (nd.op == 1) return pk::X_COL | ((uint32_t)nd.col << 8) | (uint32_t)(nd.rot + 128);
-      return pk::X_SLOT | (uint32_t)slot_of[id];
-    };
     for (size_t t = 0; t < order.size(); t++) {
       const Node& nd = nodes[order[t]];
+      auto operand = [&](int id) -> uint32_t {
+        const Node& o = nodes[id];
+        if (o.op == 0) return pk::X_CONST | (uint32_t)o.cidx;
+        if (o.op == 1) return pk::X_COL | ((uint32_t)o.col << 8) | (uint32_t)(o.rot + 128);
+        if (at[id] + 1 == (int)t) return pk::X_PREV;
+        return pk::X_SLOT | (uint32_t)slot_of[id];
+      };
       const uint32_t a = operand(nd.a), b = operand(nd.b);
       // operands dying here free their slots before the destination is chosen (the kernel reads both first)
       for (int src : {nd.a, nd.b})
@@ -553,17 +576,19 @@ struct ExprProgram {
           free_slots.push_back((uint32_t)slot_of[src]);
           slot_of[src] = -2;
         }
-      uint32_t dst;
-      if (!free_slots.empty()) {
-        dst = free_slots.back();
-        free_slots.pop_back();
-      } else {
-        dst = nslots++;
+      uint32_t dst = pk::X_NO_STORE;
+      if (wants_slot[order[t]]) {
+        if (!free_slots.empty()) {
+          dst = free_slots.back();
+          free_slots.pop_back();
+        } else {
+          dst = nslots++;
+        }
+        slot_of[order[t]] = (int)dst;
       }
-      slot_of[order[t]] = (int)dst;
       code.push_back({((uint32_t)(nd.op - 2) << 24) | dst, a, b});
     }
-    if (order.empty()) fail(H2_EINVAL, "empty quotient program");
+    if (nslots == 0) nslots = 1;
   }
 };
 
@@ -758,6 +783,82 @@ const DomainKit& domain_kit(const Domain& D, int bf, DevCtx* ctx) {
   return *g_kits.back();
 }
 
+// the permutation columns, d - 2 per grand product (halo2's chunking), and the blinding rows: host data of a key
+void key_shape(ProvingKey& K) {
+  const Circuit& C = *K.circuit;
+  K.bf = C.blinding_factors();
+  const int chunk = C.degree - 2;
+  for (size_t s = 0; s < C.permutation_columns.size(); s += chunk) {
+    std::vector<int> set;
+    for (size_t j = s; j < std::min(s + chunk, C.permutation_columns.size()); j++) set.push_back((int)j);
+    K.sets.push_back(set);
+  }
+}
+
+// every gate, the permutation argument, the y-fold and the division by X^n - 1 as one program (host only)
+void build_quotient_program(ProvingKey& K) {
+  const Circuit& C = *K.circuit;
+  const size_t np = K.np();
+  ColumnMap& M = K.cmap;
+  int next = 0;
+  M.advice0 = next; next += C.num_advice;
+  M.fixed0 = next; next += C.num_fixed;
+  M.instance0 = next; next += C.num_instance;
+  M.sigma0 = next; next += (int)np;
+  M.z0 = next; next += (int)K.sets.size();
+  M.l0 = next++; M.l_last = next++; M.l_blind = next++; M.xcol = next++; M.tinv = next++;
+  M.count = next;
+  ExprProgram& X = K.prog;
+  std::function<int(const E&)> build = [&](const E& e) -> int {
+    switch (e->kind) {
+      case Expr::Const: return X.constant(e->c);
+      case Expr::Advice: return X.column(M.advice0 + e->col, e->rot);
+      case Expr::Fixed: return X.column(M.fixed0 + e->col, e->rot);
+      case Expr::Instance: return X.column(M.instance0 + e->col, e->rot);
+      case Expr::Neg: return X.sub(X.constant(Fr::zero()), build(e->a));
+      case Expr::Sum:
+        if (e->b->kind == Expr::Neg) return X.sub(build(e->a), build(e->b->a));
+        return X.add(build(e->a), build(e->b));
+      case Expr::Prod: return X.mul(build(e->a), build(e->b));
+      case Expr::Scaled: return X.mul(build(e->a), X.constant(e->c));
+    }
+    return -1;
+  };
+  const int v_y = X.variable(&K.c_y), v_beta = X.variable(&K.c_beta), v_gamma = X.variable(&K.c_gamma);
+  std::vector<int> v_bd(np);
+  K.c_beta_delta.resize(np);
+  for (size_t j = 0; j < np; j++) v_bd[j] = X.variable(&K.c_beta_delta[j]);
+  const int one = X.constant(Fr::one());
+  std::vector<int> terms;
+  for (auto& g : C.gates) terms.push_back(build(g));
+  auto colref = [&](const ColRef& cr) {
+    return X.column((cr.first == ADVICE ? M.advice0 : cr.first == FIXED ? M.fixed0 : M.instance0) + cr.second, 0);
+  };
+  if (!K.sets.empty()) {
+    const int l0 = X.column(M.l0, 0), l_last = X.column(M.l_last, 0), l_blind = X.column(M.l_blind, 0);
+    const int nsets = (int)K.sets.size();
+    auto z = [&](int i, int rot) { return X.column(M.z0 + i, rot); };
+    terms.push_back(X.mul(l0, X.sub(one, z(0, 0))));
+    terms.push_back(X.mul(l_last, X.sub(X.mul(z(nsets - 1, 0), z(nsets - 1, 0)), z(nsets - 1, 0))));
+    for (int i = 1; i < nsets; i++) terms.push_back(X.mul(l0, X.sub(z(i, 0), z(i - 1, -(K.bf + 1)))));
+    const int l_active = X.sub(X.sub(one, l_last), l_blind);
+    const int xc = X.column(M.xcol, 0);
+    for (int i = 0; i < nsets; i++) {
+      int left = z(i, 1), right = z(i, 0);
+      for (int j : K.sets[i]) {
+        const int v = colref(C.permutation_columns[j]);
+        left = X.mul(left, X.add(X.add(v, X.mul(X.column(M.sigma0 + j, 0), v_beta)), v_gamma));
+        right = X.mul(right, X.add(X.add(v, X.mul(xc, v_bd[j])), v_gamma));
+      }
+      terms.push_back(X.mul(l_active, X.sub(left, right)));
+    }
+  }
+  int numer = terms[0];
+  for (size_t t = 1; t < terms.size(); t++) numer = X.add(X.mul(numer, v_y), terms[t]);
+  const int root = X.mul(numer, X.column(M.tinv, 0));
+  X.compile(root);
+}
+
 std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> circuit, DevCtx* ctx) {
   Trace trace("keygen");
   auto pkp = std::make_unique<ProvingKey>();
@@ -770,14 +871,8 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   K.dev = std::make_unique<Dev>(ctx);
   Dev& d = *K.dev;
   const uint32_t n = D.n;
-  K.bf = C.blinding_factors();
+  key_shape(K);
   if ((uint32_t)(K.bf + 1) >= n) fail(H2_EINVAL, "k too small for this circuit");
-  const int chunk = C.degree - 2;
-  for (size_t s = 0; s < C.permutation_columns.size(); s += chunk) {
-    std::vector<int> set;
-    for (size_t j = s; j < std::min(s + chunk, C.permutation_columns.size()); j++) set.push_back((int)j);
-    K.sets.push_back(set);
-  }
   const size_t nf = K.nf(), np = K.np();
   // fixed columns; the minimum rows a circuit needs are checked against n here
   std::vector<SparseCol> fixed = C.synthesize_fixed();
@@ -876,65 +971,8 @@ std::unique_ptr<ProvingKey> keygen(const Params& P, std::unique_ptr<Circuit> cir
   K.transcript_repr = vk_transcript_repr(s);
   trace.mark("vk digest");
 
-  // ---- the quotient program ---------------------------------------------------------------------------------------
-  ColumnMap& M = K.cmap;
-  int next = 0;
-  M.advice0 = next; next += C.num_advice;
-  M.fixed0 = next; next += C.num_fixed;
-  M.instance0 = next; next += C.num_instance;
-  M.sigma0 = next; next += (int)np;
-  M.z0 = next; next += (int)K.sets.size();
-  M.l0 = next++; M.l_last = next++; M.l_blind = next++; M.xcol = next++; M.tinv = next++;
-  M.count = next;
+  build_quotient_program(K);
   ExprProgram& X = K.prog;
-  std::function<int(const E&)> build = [&](const E& e) -> int {
-    switch (e->kind) {
-      case Expr::Const: return X.constant(e->c);
-      case Expr::Advice: return X.column(M.advice0 + e->col, e->rot);
-      case Expr::Fixed: return X.column(M.fixed0 + e->col, e->rot);
-      case Expr::Instance: return X.column(M.instance0 + e->col, e->rot);
-      case Expr::Neg: return X.sub(X.constant(Fr::zero()), build(e->a));
-      case Expr::Sum:
-        if (e->b->kind == Expr::Neg) return X.sub(build(e->a), build(e->b->a));
-        return X.add(build(e->a), build(e->b));
-      case Expr::Prod: return X.mul(build(e->a), build(e->b));
-      case Expr::Scaled: return X.mul(build(e->a), X.constant(e->c));
-    }
-    return -1;
-  };
-  const int v_y = X.variable(&K.c_y), v_beta = X.variable(&K.c_beta), v_gamma = X.variable(&K.c_gamma);
-  std::vector<int> v_bd(np);
-  K.c_beta_delta.resize(np);
-  for (size_t j = 0; j < np; j++) v_bd[j] = X.variable(&K.c_beta_delta[j]);
-  const int one = X.constant(Fr::one());
-  std::vector<int> terms;
-  for (auto& g : C.gates) terms.push_back(build(g));
-  auto colref = [&](const ColRef& cr) {
-    return X.column((cr.first == ADVICE ? M.advice0 : cr.first == FIXED ? M.fixed0 : M.instance0) + cr.second, 0);
-  };
-  if (!K.sets.empty()) {
-    const int l0 = X.column(M.l0, 0), l_last = X.column(M.l_last, 0), l_blind = X.column(M.l_blind, 0);
-    const int nsets = (int)K.sets.size();
-    auto z = [&](int i, int rot) { return X.column(M.z0 + i, rot); };
-    terms.push_back(X.mul(l0, X.sub(one, z(0, 0))));
-    terms.push_back(X.mul(l_last, X.sub(X.mul(z(nsets - 1, 0), z(nsets - 1, 0)), z(nsets - 1, 0))));
-    for (int i = 1; i < nsets; i++) terms.push_back(X.mul(l0, X.sub(z(i, 0), z(i - 1, -(K.bf + 1)))));
-    const int l_active = X.sub(X.sub(one, l_last), l_blind);
-    const int xc = X.column(M.xcol, 0);
-    for (int i = 0; i < nsets; i++) {
-      int left = z(i, 1), right = z(i, 0);
-      for (int j : K.sets[i]) {
-        const int v = colref(C.permutation_columns[j]);
-        left = X.mul(left, X.add(X.add(v, X.mul(X.column(M.sigma0 + j, 0), v_beta)), v_gamma));
-        right = X.mul(right, X.add(X.add(v, X.mul(xc, v_bd[j])), v_gamma));
-      }
-      terms.push_back(X.mul(l_active, X.sub(left, right)));
-    }
-  }
-  int numer = terms[0];
-  for (size_t t = 1; t < terms.size(); t++) numer = X.add(X.mul(numer, v_y), terms[t]);
-  const int root = X.mul(numer, X.column(M.tinv, 0));
-  X.compile(root);
   K.d_code = (const pk::XInstr*)d.upload(X.code.data(), X.code.size() * sizeof(pk::XInstr));
   trace.mark("program compiled");     // no synchronisation here: create_proof queues behind keygen's kernels on the same
                                       // stream, and the staged host copies of the uploads live as long as the key
@@ -2054,6 +2092,23 @@ int h2_selftest_host(int what, const uint8_t* in, size_t in_len, uint8_t* out, s
       r.resize(32);
       repr.to_le_bytes(r.data());
       r.insert(r.end(), s.begin(), s.end());
+    } else if (what == 6) {                // quotient program of circuit in[0]: u32 x 5 = instructions, products, column
+      if (in_len != 1) return H2_EINVAL;   // reads, LDS slots, constants; then the code (12 bytes per instruction)
+      ProvingKey K;
+      if (in[0] == 0) K.circuit = std::make_unique<CollatzCircuit>();
+      else if (in[0] == 1) K.circuit = std::make_unique<ArithmeticCircuit>();
+      else K.circuit = std::make_unique<PoseidonCircuit>();
+      key_shape(K);
+      build_quotient_program(K);
+      uint32_t st[5] = {(uint32_t)K.prog.code.size(), 0, 0, K.prog.nslots, (uint32_t)K.prog.consts.size()};
+      for (auto& ins : K.prog.code) {
+        if ((ins.op_dst >> 24) == 2) st[1]++;
+        if ((ins.a & (3u << 30)) == pk::X_COL) st[2]++;
+        if ((ins.b & (3u << 30)) == pk::X_COL) st[2]++;
+      }
+      r.resize(20 + K.prog.code.size() * sizeof(pk::XInstr));
+      memcpy(r.data(), st, 20);
+      memcpy(r.data() + 20, K.prog.code.data(), K.prog.code.size() * sizeof(pk::XInstr));
     } else if (what == 5) {                // pairing check on two (G1, G2) pairs: 2 x (64 + 128) canonical bytes -> 1 byte
       if (in_len != 2 * 192) return H2_EINVAL;
       std::vector<std::pair<G1, bn::G2>> pairs;

@@ -274,14 +274,19 @@ scan_apply_kernel(ScanBatch B, int mode, uint32_t n, uint32_t L, uint32_t C, con
 }
 
 // ---- the quotient numerator as a straight-line program -----------------------------------------------------------------
-// operand word: bits 31..30 = kind (0 slot, 1 constant, 2 column); slot / constant: index in bits 29..0;
+// operand word: bits 31..30 = kind (0 slot, 1 constant, 2 column, 3 the previous instruction's result); slot / constant: index in bits 29..0;
 // column: index in bits 29..8, rotation + 128 in bits 7..0.  op_dst: op in bits 31..24 (0 add, 1 sub, 2 mul), slot in 23..0.
 struct XInstr {
   uint32_t op_dst, a, b;
 };
-constexpr uint32_t X_SLOT = 0u << 30, X_CONST = 1u << 30, X_COL = 2u << 30;
+constexpr uint32_t X_SLOT = 0u << 30, X_CONST = 1u << 30, X_COL = 2u << 30, X_PREV = 3u << 30;
+constexpr uint32_t X_NO_STORE = 0xFFFFFFu;     // destination field of a result that only the next instruction reads
 constexpr int EXPR_BLOCK = 128;
 
+// Operands that do not depend on the program's own results -- columns and constants -- are fetched TWO instructions
+// ahead: a block is one wave per SIMD (the LDS slots of 128 rows fill half a CU), so nothing else hides the ~0.5-2 us
+// of a global load, and the Poseidon program reads a column for 87 of its 183 instructions (1.5 ms for 2^19 rows
+// before, of which the arithmetic is about a third).
 static __global__ void __launch_bounds__(EXPR_BLOCK)
 expr_kernel(const XInstr* __restrict__ prog, uint32_t ninstr, const U128* const* __restrict__ cols,
             const uint32_t* __restrict__ col_mask, const U128* __restrict__ consts, U128* __restrict__ out, uint32_t step,
@@ -295,24 +300,40 @@ expr_kernel(const XInstr* __restrict__ prog, uint32_t ninstr, const U128* const*
     for (int l = 0; l < 8; l++) r.v[l] = slots[(s * 8 + l) * EXPR_BLOCK + tid];
     return r;
   };
-  auto operand = [&](uint32_t code) -> F {
+  // a column or constant operand (a slot operand is read when its instruction runs: it may be the result just before)
+  auto fetch = [&](uint32_t code) -> F {
     const uint32_t kind = code & (3u << 30);
-    if (kind == X_SLOT) return slot_load(code & 0x3FFFFFFFu);
+    if (kind == X_SLOT || kind == X_PREV) return F::zero();
     if (kind == X_CONST) return fe_load<FR>(consts + 2 * (size_t)(code & 0x3FFFFFFFu));
     const uint32_t c = (code >> 8) & 0x3FFFFFu;
     const int rot = (int)(code & 0xFFu) - 128;
     const uint32_t idx = (i + (uint32_t)(rot * (int)step)) & col_mask[c];
     return fe_load<FR>(cols[c] + 2 * (size_t)idx);
   };
+  const XInstr nop{0u, X_SLOT, X_SLOT};
+  auto instr_at = [&](uint32_t k) { return k < ninstr ? prog[k] : nop; };
   F r = F::zero();
-  for (uint32_t k = 0; k < ninstr; k++) {
-    const XInstr ins = prog[k];
-    const F a = operand(ins.a), b = operand(ins.b);
+  // one instruction: operands from the prefetched pair or from LDS; then the pair is refilled for instruction k + 2
+  auto run = [&](uint32_t k, const XInstr& ins, F& pa, F& pb) {
+    const uint32_t ka = ins.a & (3u << 30), kb = ins.b & (3u << 30);
+    const F a = ka == X_SLOT ? slot_load(ins.a & 0x3FFFFFFFu) : ka == X_PREV ? r : pa;
+    const F b = kb == X_SLOT ? slot_load(ins.b & 0x3FFFFFFFu) : kb == X_PREV ? r : pb;
+    const XInstr ahead = instr_at(k + 2);
+    pa = fetch(ahead.a);
+    pb = fetch(ahead.b);
     const uint32_t op = ins.op_dst >> 24;
     r = op == 0 ? fe_add(a, b) : op == 1 ? fe_sub(a, b) : fe_mul(a, b);
     const uint32_t s = ins.op_dst & 0xFFFFFFu;
+    if (s != X_NO_STORE) {
 #pragma unroll
-    for (int l = 0; l < 8; l++) slots[(s * 8 + l) * EXPR_BLOCK + tid] = r.v[l];
+      for (int l = 0; l < 8; l++) slots[(s * 8 + l) * EXPR_BLOCK + tid] = r.v[l];
+    }
+  };
+  XInstr i0 = instr_at(0), i1 = instr_at(1);
+  F pa0 = fetch(i0.a), pb0 = fetch(i0.b), pa1 = fetch(i1.a), pb1 = fetch(i1.b);
+  for (uint32_t k = 0; k < ninstr; k += 2) {
+    run(k, instr_at(k), pa0, pb0);
+    if (k + 1 < ninstr) run(k + 1, instr_at(k + 1), pa1, pb1);
   }
   if (i < en) fe_store<FR>(out + 2 * (size_t)i, r);     // a domain smaller than one block: the spare lanes computed on wrapped rows
 }
