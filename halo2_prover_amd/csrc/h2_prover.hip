@@ -514,13 +514,14 @@ struct ExprProgram {
   int mul(int a, int b) { return intern({4, std::min(a, b), std::max(a, b), -1, 0, -1}); }
 
   std::vector<pk::XInstr> code;
-  uint32_t nslots = 0;
+  uint32_t nslots = 0, nreduce = 0;      // LDS slots; products with one inserted to keep magnitudes bounded
   // emit instructions for `root` (every arithmetic node it depends on, in order), slots reused after the last use.
   // Order: depth first, the operand that needs more live values first (Sethi-Ullman numbering; shared nodes count as
   // computed).  A result that the NEXT instruction consumes is handed over in a register (operand kind X_PREV), and a
   // result with no other use is never stored: a slot costs 32 bytes of LDS per row and the slots of 128 rows decide
   // how many blocks share a CU (h2_prover_kernels.hpp, expr_kernel).
   void compile(int root) {
+    (void)constant(Fr::one());                       // the reducing product's operand: interned before the node tables are sized
     std::vector<int> need(nodes.size(), -1);
     std::function<int(int)> su = [&](int id) -> int {
       if (need[id] >= 0) return need[id];
@@ -560,6 +561,14 @@ struct ExprProgram {
       }
     std::vector<int> slot_of(nodes.size(), -1);
     std::vector<uint32_t> free_slots;
+    // magnitudes in units of p (expr_kernel's header): constants are canonical, columns below EXPR_COLUMN_BOUND, a
+    // product of a and b below a b / 128 + 1 (p^2 / 2^261 < p / 128); a sum that would pass EXPR_VALUE_BOUND is
+    // multiplied by one straight away
+    std::vector<double> bound(nodes.size(), 0.0);
+    for (size_t id = 0; id < nodes.size(); id++)
+      if (nodes[id].op == 0) bound[id] = 1.0;
+      else if (nodes[id].op == 1) bound[id] = pk::EXPR_COLUMN_BOUND;
+    const uint32_t one_operand = pk::X_CONST | (uint32_t)nodes[constant(Fr::one())].cidx;
     for (size_t t = 0; t < order.size(); t++) {
       const Node& nd = nodes[order[t]];
       auto operand = [&](int id) -> uint32_t {
@@ -586,7 +595,16 @@ struct ExprProgram {
         }
         slot_of[order[t]] = (int)dst;
       }
-      code.push_back({((uint32_t)(nd.op - 2) << 24) | dst, a, b});
+      double bd = nd.op == 4 ? bound[nd.a] * bound[nd.b] / 128.0 + 1.0 : bound[nd.a] + bound[nd.b];
+      if (nd.op != 4 && bd > pk::EXPR_VALUE_BOUND) {
+        code.push_back({((uint32_t)(nd.op - 2) << 24) | pk::X_NO_STORE, a, b});
+        code.push_back({(2u << 24) | dst, pk::X_PREV, one_operand});
+        bd = bd / 128.0 + 1.0;
+        nreduce++;
+      } else {
+        code.push_back({((uint32_t)(nd.op - 2) << 24) | dst, a, b});
+      }
+      bound[order[t]] = bd;
     }
     if (nslots == 0) nslots = 1;
   }
@@ -1157,8 +1175,11 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
     for (size_t j = 0; j < np; j++) consts[K.c_beta_delta[j]] = beta * delta.pow_u64((uint64_t)j);
     const U128* const* d_ptrs = (const U128* const*)d.upload(ptrs.data(), ptrs.size() * sizeof(void*));
     const uint32_t* d_masks = (const uint32_t*)d.upload(masks.data(), masks.size() * 4);
+    for (auto& c : consts)
+      for (int t = 0; t < 5; t++) c = c + c;            // c 2^256 -> c 2^261: the kernel's working form (R' = 2^261)
     Col d_consts = d.upload_frs(consts);
-    const size_t lds = (size_t)K.prog.nslots * 8 * pk::EXPR_BLOCK * 4;
+    const size_t lds_slots = K.prog.nslots > (uint32_t)pk::EXPR_REG_SLOTS ? K.prog.nslots - pk::EXPR_REG_SLOTS : 1;
+    const size_t lds = lds_slots * 9 * pk::EXPR_BLOCK * 4;
     if (lds > 160 * 1024) fail(H2_EINVAL, "quotient program needs too many live values");
     hipLaunchKernelGGL(pk::expr_kernel, dim3((en + pk::EXPR_BLOCK - 1) / pk::EXPR_BLOCK), dim3(pk::EXPR_BLOCK), lds, d.s, K.d_code,
                        (uint32_t)K.prog.code.size(), d_ptrs, d_masks, d_consts, h_ext, en / n, en);
@@ -2092,23 +2113,23 @@ int h2_selftest_host(int what, const uint8_t* in, size_t in_len, uint8_t* out, s
       r.resize(32);
       repr.to_le_bytes(r.data());
       r.insert(r.end(), s.begin(), s.end());
-    } else if (what == 6) {                // quotient program of circuit in[0]: u32 x 5 = instructions, products, column
-      if (in_len != 1) return H2_EINVAL;   // reads, LDS slots, constants; then the code (12 bytes per instruction)
+    } else if (what == 6) {                // quotient program of circuit in[0]: u32 x 6 = instructions, products, column
+      if (in_len != 1) return H2_EINVAL;   // reads, LDS slots, constants, inserted reductions; then the code (12 bytes each)
       ProvingKey K;
       if (in[0] == 0) K.circuit = std::make_unique<CollatzCircuit>();
       else if (in[0] == 1) K.circuit = std::make_unique<ArithmeticCircuit>();
       else K.circuit = std::make_unique<PoseidonCircuit>();
       key_shape(K);
       build_quotient_program(K);
-      uint32_t st[5] = {(uint32_t)K.prog.code.size(), 0, 0, K.prog.nslots, (uint32_t)K.prog.consts.size()};
+      uint32_t st[6] = {(uint32_t)K.prog.code.size(), 0, 0, K.prog.nslots, (uint32_t)K.prog.consts.size(), K.prog.nreduce};
       for (auto& ins : K.prog.code) {
         if ((ins.op_dst >> 24) == 2) st[1]++;
         if ((ins.a & (3u << 30)) == pk::X_COL) st[2]++;
         if ((ins.b & (3u << 30)) == pk::X_COL) st[2]++;
       }
-      r.resize(20 + K.prog.code.size() * sizeof(pk::XInstr));
-      memcpy(r.data(), st, 20);
-      memcpy(r.data() + 20, K.prog.code.data(), K.prog.code.size() * sizeof(pk::XInstr));
+      r.resize(24 + K.prog.code.size() * sizeof(pk::XInstr));
+      memcpy(r.data(), st, 24);
+      memcpy(r.data() + 24, K.prog.code.data(), K.prog.code.size() * sizeof(pk::XInstr));
     } else if (what == 5) {                // pairing check on two (G1, G2) pairs: 2 x (64 + 128) canonical bytes -> 1 byte
       if (in_len != 2 * 192) return H2_EINVAL;
       std::vector<std::pair<G1, bn::G2>> pairs;

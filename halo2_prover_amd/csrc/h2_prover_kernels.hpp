@@ -15,6 +15,7 @@
 // All HBM-bound elementwise work except expr_kernel (a few hundred field products per row).
 #pragma once
 #include "h2_field.hpp"
+#include "h2_field29.hpp"
 
 namespace h2 {
 namespace pk {
@@ -274,33 +275,84 @@ scan_apply_kernel(ScanBatch B, int mode, uint32_t n, uint32_t L, uint32_t C, con
 }
 
 // ---- the quotient numerator as a straight-line program -----------------------------------------------------------------
-// operand word: bits 31..30 = kind (0 slot, 1 constant, 2 column, 3 the previous instruction's result); slot / constant: index in bits 29..0;
-// column: index in bits 29..8, rotation + 128 in bits 7..0.  op_dst: op in bits 31..24 (0 add, 1 sub, 2 mul), slot in 23..0.
+// operand word: bits 31..30 = kind (0 slot, 1 constant, 2 column, 3 the previous instruction's result); slot / constant:
+// index in bits 29..0; column: index in bits 29..8, rotation + 128 in bits 7..0.
+// op_dst: op in bits 31..24 (0 add, 1 sub, 2 mul), slot in 23..0 (X_NO_STORE: only the next instruction reads it).
 struct XInstr {
   uint32_t op_dst, a, b;
 };
 constexpr uint32_t X_SLOT = 0u << 30, X_CONST = 1u << 30, X_COL = 2u << 30, X_PREV = 3u << 30;
 constexpr uint32_t X_NO_STORE = 0xFFFFFFu;     // destination field of a result that only the next instruction reads
-constexpr int EXPR_BLOCK = 128;
+constexpr int EXPR_BLOCK = 64;
+constexpr int EXPR_REG_SLOTS = 4;       // slots kept in registers (expr_kernel); the rest is LDS
+// magnitudes, in units of p, that the host's compiler (ExprProgram::compile) assumes: a column operand after
+// expr_column_operand, and the largest value an instruction may produce before it is reduced by a product with one
+constexpr int EXPR_COLUMN_BOUND = 16, EXPR_VALUE_BOUND = 32;
+
+// The arithmetic runs on the 9 x 29-bit lazy form (h2_field29.hpp: for bn256::Fr a product is ~240 instructions
+// against ~600 on 8 x 32-bit limbs with carries):
+//   * a column holds x 2^256 (canonical); shifted left by five bits while it is unpacked that is the integer
+//     x 2^261 + (a multiple of p) < 32 p, the working form of x -- minus 16 p it lies in (-16 p, 16 p);
+//   * the constant table is uploaded in the working form (c 2^261 mod p, canonical) and only unpacked;
+//   * sums and differences are carry-normalised, products need nothing; the compiler keeps every value below
+//     EXPR_VALUE_BOUND p (it multiplies by one where a sum would exceed it), so every product has operands far below
+//     the 64 p that fe29_mul and fe29_to_api allow;
+//   * the last result goes back to the API form (one product) on its way out.
+template <class FP>
+__device__ __forceinline__ Fe29<FP> expr_column_operand(const Fe<FP>& a) {
+  Fe29<FP> r;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    // limb j of (a << 5): bits [29 j - 5, 29 j + 24) of a
+    const int bit = 29 * j - 5;
+    uint32_t limb;
+    if (bit < 0) {
+      limb = (a.v[0] << 5) & L29_MASK;
+    } else {
+      const int w = bit >> 5, sh = bit & 31;
+      const uint64_t lo = a.v[w], hi = w + 1 < 8 ? a.v[w + 1] : 0;
+      limb = (uint32_t)((lo | (hi << 32)) >> sh) & L29_MASK;
+    }
+    // minus 16 p = (p << 4): limb j of it is bits [29 j - 4, 29 j + 25) of p
+    const int pb = 29 * j - 4;
+    uint32_t pl;
+    if (pb < 0) {
+      pl = (FP::P(0) << 4) & L29_MASK;
+    } else {
+      const int w = pb >> 5, sh = pb & 31;
+      const uint64_t lo = w < 8 ? FP::P(w) : 0, hi = w + 1 < 8 ? FP::P(w + 1) : 0;
+      pl = (uint32_t)((lo | (hi << 32)) >> sh) & L29_MASK;
+    }
+    r.v[j] = (int32_t)limb - (int32_t)pl;
+  }
+  return r;
+}
 
 // Operands that do not depend on the program's own results -- columns and constants -- are fetched TWO instructions
-// ahead: a block is one wave per SIMD (the LDS slots of 128 rows fill half a CU), so nothing else hides the ~0.5-2 us
-// of a global load, and the Poseidon program reads a column for 87 of its 183 instructions (1.5 ms for 2^19 rows
-// before, of which the arithmetic is about a third).
+// ahead (a global load is 0.5-2 us, an instruction 0.1-0.5).  LDS: 36 bytes per slot beyond the register slots and row.
 static __global__ void __launch_bounds__(EXPR_BLOCK)
 expr_kernel(const XInstr* __restrict__ prog, uint32_t ninstr, const U128* const* __restrict__ cols,
             const uint32_t* __restrict__ col_mask, const U128* __restrict__ consts, U128* __restrict__ out, uint32_t step,
             uint32_t en) {
-  extern __shared__ uint32_t slots[];     // [slot][limb][thread]
+  using W = Fe29<FR>;
+  extern __shared__ int32_t slots[];      // [slot][limb][thread]
   const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * EXPR_BLOCK + tid;
+  // slots 0 .. EXPR_REG_SLOTS-1 live in registers: the slot number comes from the instruction word, the same for the
+  // whole wave, so the choice is a scalar branch around nine moves -- nothing next to a 240-instruction product, and
+  // the LDS that is left (Poseidon: 3 slots instead of 7) no longer caps the waves per SIMD
+  W reg0 = W::zero(), reg1 = W::zero(), reg2 = W::zero(), reg3 = W::zero();
   auto slot_load = [&](uint32_t s) {
-    F r;
+    if (s == 0) return reg0;
+    if (s == 1) return reg1;
+    if (s == 2) return reg2;
+    if (s == 3) return reg3;
+    W r;
 #pragma unroll
-    for (int l = 0; l < 8; l++) r.v[l] = slots[(s * 8 + l) * EXPR_BLOCK + tid];
+    for (int l = 0; l < 9; l++) r.v[l] = slots[((s - EXPR_REG_SLOTS) * 9 + l) * EXPR_BLOCK + tid];
     return r;
   };
-  // a column or constant operand (a slot operand is read when its instruction runs: it may be the result just before)
+  // a column or constant operand as loaded (a slot operand is read when its instruction runs)
   auto fetch = [&](uint32_t code) -> F {
     const uint32_t kind = code & (3u << 30);
     if (kind == X_SLOT || kind == X_PREV) return F::zero();
@@ -312,30 +364,43 @@ expr_kernel(const XInstr* __restrict__ prog, uint32_t ninstr, const U128* const*
   };
   const XInstr nop{0u, X_SLOT, X_SLOT};
   auto instr_at = [&](uint32_t k) { return k < ninstr ? prog[k] : nop; };
-  F r = F::zero();
-  // one instruction: operands from the prefetched pair or from LDS; then the pair is refilled for instruction k + 2
-  auto run = [&](uint32_t k, const XInstr& ins, F& pa, F& pb) {
-    const uint32_t ka = ins.a & (3u << 30), kb = ins.b & (3u << 30);
-    const F a = ka == X_SLOT ? slot_load(ins.a & 0x3FFFFFFFu) : ka == X_PREV ? r : pa;
-    const F b = kb == X_SLOT ? slot_load(ins.b & 0x3FFFFFFFu) : kb == X_PREV ? r : pb;
+  W r = W::zero();
+  auto operand = [&](uint32_t code, const F& pre) -> W {
+    const uint32_t kind = code & (3u << 30);
+    if (kind == X_SLOT) return slot_load(code & 0x3FFFFFFFu);
+    if (kind == X_PREV) return r;
+    if (kind == X_CONST) return fe29_unpack(pre);
+    return expr_column_operand(pre);
+  };
+  // one instruction: operands from the prefetched pair, the register or LDS; the pair is refilled for instruction k + 2
+  // (the instruction words travel the same way: `ins` was read two instructions ago and is replaced by the one two ahead)
+  auto run = [&](uint32_t k, XInstr& slot_ins, F& pa, F& pb) {
+    const XInstr ins = slot_ins;
+    const W a = operand(ins.a, pa), b = operand(ins.b, pb);
     const XInstr ahead = instr_at(k + 2);
+    slot_ins = ahead;
     pa = fetch(ahead.a);
     pb = fetch(ahead.b);
     const uint32_t op = ins.op_dst >> 24;
-    r = op == 0 ? fe_add(a, b) : op == 1 ? fe_sub(a, b) : fe_mul(a, b);
+    if (op == 2) r = fe29_mul(a, b);
+    else r = fe29_norm(op == 0 ? fe29_add(a, b) : fe29_sub(a, b));
     const uint32_t s = ins.op_dst & 0xFFFFFFu;
-    if (s != X_NO_STORE) {
+    if (s == 0) reg0 = r;
+    else if (s == 1) reg1 = r;
+    else if (s == 2) reg2 = r;
+    else if (s == 3) reg3 = r;
+    else if (s != X_NO_STORE) {
 #pragma unroll
-      for (int l = 0; l < 8; l++) slots[(s * 8 + l) * EXPR_BLOCK + tid] = r.v[l];
+      for (int l = 0; l < 9; l++) slots[((s - EXPR_REG_SLOTS) * 9 + l) * EXPR_BLOCK + tid] = r.v[l];
     }
   };
   XInstr i0 = instr_at(0), i1 = instr_at(1);
   F pa0 = fetch(i0.a), pb0 = fetch(i0.b), pa1 = fetch(i1.a), pb1 = fetch(i1.b);
   for (uint32_t k = 0; k < ninstr; k += 2) {
-    run(k, instr_at(k), pa0, pb0);
-    if (k + 1 < ninstr) run(k + 1, instr_at(k + 1), pa1, pb1);
+    run(k, i0, pa0, pb0);
+    if (k + 1 < ninstr) run(k + 1, i1, pa1, pb1);
   }
-  if (i < en) fe_store<FR>(out + 2 * (size_t)i, r);     // a domain smaller than one block: the spare lanes computed on wrapped rows
+  if (i < en) fe_store<FR>(out + 2 * (size_t)i, fe29_to_api(r));     // a domain smaller than one block: the spare lanes computed on wrapped rows
 }
 
 }  // namespace pk

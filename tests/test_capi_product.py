@@ -144,6 +144,47 @@ def test_pairing_check_in_c_agrees_with_the_python_pairing(lib):
     assert PR.pairing_check([(_g1_mul(a, (1, 2)), _G2_GEN), ((1, 2), neg)])
 
 
+def test_quotient_programs_are_well_formed_and_need_few_live_values(lib):
+    """ExprProgram::compile (h2_prover.hip): the straight-line program expr_kernel interprets.  Structure only here (the
+    GPU tests below check its results through byte-identical proofs): operands refer to values that exist, a result
+    without a slot is read by the very next instruction, and the live values stay few -- they are 36 bytes of LDS or
+    nine registers per row each, which is what decides the kernel's occupancy."""
+    import struct
+    SLOT, CONST, COL, PREV, NO_STORE = 0, 1, 2, 3, 0xFFFFFF
+    for circuit, max_slots in ((0, 3), (1, 4), (2, 8)):
+        raw = host(lib, 6, bytes([circuit]))
+        n_instr, n_mul, n_col, n_slots, n_consts, n_reduce = struct.unpack("<6I", raw[:24])
+        code = [struct.unpack("<3I", raw[24 + 12 * i: 36 + 12 * i]) for i in range(n_instr)]
+        assert len(raw) == 24 + 12 * n_instr and n_instr > 0
+        assert n_slots <= max_slots and n_reduce <= 4
+        written = set()
+        muls = cols = 0
+        for t, (op_dst, a, b) in enumerate(code):
+            op, dst = op_dst >> 24, op_dst & 0xFFFFFF
+            assert op in (0, 1, 2)
+            muls += op == 2
+            for operand in (a, b):
+                kind, low = operand >> 30, operand & 0x3FFFFFFF
+                if kind == SLOT:
+                    assert low in written, (circuit, t)
+                elif kind == CONST:
+                    assert low < n_consts
+                elif kind == COL:
+                    cols += 1
+                    assert -64 < (low & 0xFF) - 128 < 64
+                else:
+                    assert t > 0
+            if dst == NO_STORE and t + 1 == n_instr:
+                pass                             # the root stays in the register the kernel writes out
+            elif dst == NO_STORE:
+                assert PREV in (code[t + 1][1] >> 30, code[t + 1][2] >> 30), (circuit, t)
+            else:
+                assert dst < n_slots
+                written.add(dst)
+        assert (muls, cols) == (n_mul, n_col)
+        assert code[-1][0] >> 24 == 2          # the root: numerator times 1 / (X^n - 1)
+
+
 def test_simulate_and_count(lib):
     def sim(js, idx):
         out = ctypes.create_string_buffer(256)
