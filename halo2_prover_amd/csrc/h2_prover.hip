@@ -320,7 +320,7 @@ struct Dev {
       Col ws = col((size_t)2 * cnt * pk::SCAN_CHUNKS);
       Col H = ws, G = ws + 2 * cnt * (size_t)pk::SCAN_CHUNKS;
       hipLaunchKernelGGL(pk::scan_chunk_kernel, dim3((C + 63) / 64, (unsigned)cnt), dim3(64), 0, s, B, mode, n, L, C, H);
-      hipLaunchKernelGGL(pk::scan_block_kernel, dim3((unsigned)cnt), dim3(pk::SCAN_CHUNKS), 0, s, B, mode, C, H, G);
+      hipLaunchKernelGGL(pk::scan_block_kernel, dim3((unsigned)cnt), dim3(pk::SCAN_BLOCK_THREADS), 0, s, B, mode, C, H, G);
       hipLaunchKernelGGL(pk::scan_apply_kernel, dim3((C + 63) / 64, (unsigned)cnt), dim3(64), 0, s, B, mode, n, L, C, G);
       hip_ok(hipGetLastError(), "scan_batch kernels");
       release(ws);

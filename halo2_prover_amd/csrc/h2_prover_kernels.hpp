@@ -23,6 +23,79 @@ namespace pk {
 using FR = BN254_FR;
 using F = Fe<FR>;
 
+// ---- the 9 x 29-bit lazy form (h2_field29.hpp) for bn256::Fr in these kernels ---------------------------------------------
+// A product is ~240 instructions there against ~600 on 8 x 32-bit limbs with carries, and a lone wave runs a chain of
+// them about twice as fast -- most kernels below are chains (a scan's recurrence, an inversion, a program's
+// instructions).  HBM keeps the API's form x 2^256; on the way in a value is shifted left by five bits while it is
+// unpacked, which is the integer x 2^261 + (a multiple of p) < 32 p: the working form of x; minus 16 p it lies in
+// (-16 p, 16 p) with limbs of magnitude < 2^29 (a valid operand of fe29_mul on either side).  On the way out one
+// product with 2^256 (fe29_to_api) gives the canonical API bytes back.
+using W = Fe29<FR>;
+template <class FP>
+__device__ __forceinline__ Fe29<FP> expr_column_operand(const Fe<FP>& a) {
+  Fe29<FP> r;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    // limb j of (a << 5): bits [29 j - 5, 29 j + 24) of a
+    const int bit = 29 * j - 5;
+    uint32_t limb;
+    if (bit < 0) {
+      limb = (a.v[0] << 5) & L29_MASK;
+    } else {
+      const int w = bit >> 5, sh = bit & 31;
+      const uint64_t lo = a.v[w], hi = w + 1 < 8 ? a.v[w + 1] : 0;
+      limb = (uint32_t)((lo | (hi << 32)) >> sh) & L29_MASK;
+    }
+    // minus 16 p = (p << 4): limb j of it is bits [29 j - 4, 29 j + 25) of p
+    const int pb = 29 * j - 4;
+    uint32_t pl;
+    if (pb < 0) {
+      pl = (FP::P(0) << 4) & L29_MASK;
+    } else {
+      const int w = pb >> 5, sh = pb & 31;
+      const uint64_t lo = w < 8 ? FP::P(w) : 0, hi = w + 1 < 8 ? FP::P(w + 1) : 0;
+      pl = (uint32_t)((lo | (hi << 32)) >> sh) & L29_MASK;
+    }
+    r.v[j] = (int32_t)limb - (int32_t)pl;
+  }
+  return r;
+}
+
+__device__ __forceinline__ W w_load(const U128* p) { return expr_column_operand(fe_load<FR>(p)); }
+__device__ __forceinline__ W w_from(const F& a) { return expr_column_operand(a); }
+__device__ __forceinline__ void w_store(U128* p, const W& x) { fe_store<FR>(p, fe29_to_api(x)); }
+// t in (-p, 3p), any limbs within fe29_norm's reach -> canonical, packed (the API's bytes when t is x 2^256 + j p)
+__device__ __forceinline__ F w_canonical_pack(const W& t0) {
+  W pl;
+#pragma unroll
+  for (int i = 0; i < 9; i++) pl.v[i] = (int32_t)fe29_p<FR>(i);
+  W t = fe29_norm(t0);
+  if (t.v[8] < 0) t = fe29_norm(fe29_add(t, pl));
+  W s = fe29_norm(fe29_sub(t, pl));
+  if (s.v[8] >= 0) t = s;
+  s = fe29_norm(fe29_sub(t, pl));
+  if (s.v[8] >= 0) t = s;
+  return fe29_pack(t);
+}
+// a^(p-2), two exponent bits at a time (254 squarings + ~96 products; the exponent is a constant, the branches uniform)
+__device__ __forceinline__ W w_inv(const W& a) {
+  const W a2 = fe29_mul(a, a), a3 = fe29_mul(a2, a);
+  uint32_t e[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) e[i] = FR::P(i);
+  e[0] -= 2;                                  // bn256::Fr: p[0] = 0xf0000001, no borrow
+  W r = fe29_from_api(F::one());
+  for (int i = 254; i >= 0; i -= 2) {
+    r = fe29_mul(r, r);
+    r = fe29_mul(r, r);
+    const uint32_t d = (e[i >> 5] >> (i & 31)) & 3u;
+    if (d == 1) r = fe29_mul(r, a);
+    else if (d == 2) r = fe29_mul(r, a2);
+    else if (d == 3) r = fe29_mul(r, a3);
+  }
+  return r;
+}
+
 // column[cell.row] = cell.value for `count` cells (values in Montgomery form); the column was zero-filled before
 struct CellRef {
   uint32_t col, row;
@@ -86,31 +159,34 @@ perm_ratio_kernel(PermBatch B, const U128* __restrict__ omega_col, U128* __restr
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lo = t * PERM_RUN;
   if (lo >= n) return;
-  F num[PERM_RUN], den[PERM_RUN], pre[PERM_RUN];
-  F acc = F::one();
+  const W gamma = w_from(A.gamma), beta = w_from(A.beta);
+  W num[PERM_RUN], den[PERM_RUN], pre[PERM_RUN];
+  const W one = fe29_from_api(F::one());
+  W acc = one;
 #pragma unroll
   for (int k = 0; k < PERM_RUN; k++) {
     const uint32_t i = lo + k;
-    F nu = F::one(), de = F::one();
+    W nu = one, de = one;
     if (i < n) {
-      const F w = fe_load<FR>(omega_col + 2 * (size_t)i);
+      const W w = w_load(omega_col + 2 * (size_t)i);
       for (int j = 0; j < A.ncols; j++) {
-        const F vg = fe_add(fe_load<FR>(A.value[j] + 2 * (size_t)i), A.gamma);
-        nu = fe_mul(nu, fe_add(fe_mul(w, A.beta_delta[j]), vg));
-        de = fe_mul(de, fe_add(fe_mul(fe_load<FR>(A.sigma[j] + 2 * (size_t)i), A.beta), vg));
+        // v + gamma: three terms at most 16 p + p: normalised before it enters a product as the second operand
+        const W vg = fe29_add(w_load(A.value[j] + 2 * (size_t)i), gamma);
+        nu = fe29_mul(nu, fe29_norm(fe29_add(fe29_mul(w, w_from(A.beta_delta[j])), vg)));
+        de = fe29_mul(de, fe29_norm(fe29_add(fe29_mul(w_load(A.sigma[j] + 2 * (size_t)i), beta), vg)));
       }
     }
     num[k] = nu;
     den[k] = de;
     pre[k] = acc;
-    acc = fe_mul(acc, de);
+    acc = fe29_mul(acc, de);
   }
-  F inv = fe_inv(acc);        // a zero denominator (probability 2^-250 per row) would zero the run, as 1/0 := 0 does
+  W inv = w_inv(acc);         // a zero denominator (probability 2^-250 per row) would zero the run, as 1/0 := 0 does
 #pragma unroll
   for (int k = PERM_RUN - 1; k >= 0; k--) {
     const uint32_t i = lo + k;
-    if (i < n) fe_store<FR>(ratio + 2 * (size_t)i, fe_mul(num[k], fe_mul(pre[k], inv)));
-    inv = fe_mul(inv, den[k]);
+    if (i < n) w_store(ratio + 2 * (size_t)i, fe29_mul(num[k], fe29_mul(pre[k], inv)));
+    inv = fe29_mul(inv, den[k]);
   }
 }
 
@@ -189,11 +265,11 @@ poly_eval_final_kernel(const U128* __restrict__ partial, uint32_t blocks_per_job
 }
 
 // ---- several synthetic divisions / prefix products in ONE launch sequence (grid.y = job) -------------------------------
-// The same three-kernel scans as h2_poly.hpp (chunk values, log-step scan of <= 1024 chunk values in one block,
+// The same three-kernel scans as h2_poly.hpp (chunk values, a scan of the chunk values in one block,
 // recurrence inside every chunk), for independent jobs: the opening witnesses of the GWC points, the permutation
 // sets' grand products.  Each scan is a latency chain on 16 waves; side by side they cost what one costs.
 constexpr int SCAN_MAX_JOBS = 8;
-constexpr uint32_t SCAN_CHUNKS = 1024;
+constexpr uint32_t SCAN_CHUNKS = 4096;
 struct ScanBatch {
   const U128* a[SCAN_MAX_JOBS];
   U128* out[SCAN_MAX_JOBS];
@@ -201,53 +277,133 @@ struct ScanBatch {
   F w[SCAN_MAX_JOBS];        // division only: z^L
 };
 // mode 0: q = (a - a(z)) / (X - z) (suffix sums with weights); mode 1: out[i] = prod_{j < i} a[j]
+//
+// Both on the 29-bit form (a chain of products on one wave: twice as fast there).  Mode 1 works on true values: shifted
+// loads, one extra product (fe29_to_api) per stored element, off the chain.  Mode 0 is LINEAR in the data, so the data
+// stay in the API's form read as the working form of x / 32 (plain unpack, no conversion either way): with z in the
+// true working form, acc z / R' + a keeps that scaling, and a result only needs to be made canonical to be stored.
+constexpr int SCAN_AHEAD = 4;     // elements loaded ahead of the recurrence (the chain itself cannot hide a load)
 static __global__ void __launch_bounds__(64)
 scan_chunk_kernel(ScanBatch B, int mode, uint32_t n, uint32_t L, uint32_t C, U128* __restrict__ H) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, job = blockIdx.y;
   if (c >= C) return;
   const U128* a = B.a[job];
   const uint32_t lo = c * L, hi = min(n, lo + L);
-  F acc;
+  U128* dst = H + 2 * ((size_t)job * SCAN_CHUNKS + c);
   if (mode == 0) {
-    acc = F::zero();
-    const F z = B.z[job];
-    for (uint32_t i = hi; i-- > lo;) acc = fe_add(fe_mul(acc, z), fe_load<FR>(a + 2 * (size_t)i));
+    W acc = W::zero();
+    const W z = w_from(B.z[job]);
+    for (uint32_t top = hi; top > lo;) {
+      const uint32_t cnt = min((uint32_t)SCAN_AHEAD, top - lo);
+      F v[SCAN_AHEAD];
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) v[k] = fe_load<FR>(a + 2 * (size_t)(top - 1 - k));
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) acc = fe29_add(fe29_mul(acc, z), fe29_unpack(v[k]));
+      top -= cnt;
+    }
+    fe_store<FR>(dst, w_canonical_pack(acc));
   } else {
-    acc = F::one();
-    for (uint32_t i = lo; i < hi; i++) acc = fe_mul(acc, fe_load<FR>(a + 2 * (size_t)i));
+    W acc = fe29_from_api(F::one());
+    for (uint32_t at = lo; at < hi;) {
+      const uint32_t cnt = min((uint32_t)SCAN_AHEAD, hi - at);
+      F v[SCAN_AHEAD];
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) v[k] = fe_load<FR>(a + 2 * (size_t)(at + k));
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) acc = fe29_mul(acc, w_from(v[k]));
+      at += cnt;
+    }
+    w_store(dst, acc);
   }
-  fe_store<FR>(H + 2 * ((size_t)job * SCAN_CHUNKS + c), acc);
 }
-static __global__ void __launch_bounds__(1024)
+// Scan of the C <= SCAN_CHUNKS chunk values in one block of SCAN_BLOCK_THREADS threads: every thread takes
+// SCAN_PER_THREAD consecutive values (a short recurrence in registers), the group totals go through a log-step scan
+// in LDS (unpacked, 36 bytes each), and the thread finishes its own values.  The block is a chain of products on ONE
+// CU: measured 69 us with 1024 threads x 4 values (16 waves queue for four SIMDs), 74 us with 256 x 16 (long local
+// recurrences), 61 us with 512 x 8.  With 4096 chunks of 16 elements the three kernels take 17 + 61 + 28 us for the
+// four opening quotients of a proof; with 1024 chunks of 64 they took 58 + 40 + 65.
+constexpr int SCAN_BLOCK_THREADS = 512;
+constexpr int SCAN_PER_THREAD = SCAN_CHUNKS / SCAN_BLOCK_THREADS;
+static __global__ void __launch_bounds__(SCAN_BLOCK_THREADS)
 scan_block_kernel(ScanBatch B, int mode, uint32_t C, const U128* __restrict__ H, U128* __restrict__ G) {
-  __shared__ U128 lds[2 * SCAN_CHUNKS];
-  const uint32_t c = threadIdx.x, job = blockIdx.x;
+  __shared__ int32_t lds[9 * SCAN_BLOCK_THREADS];   // [limb][thread]
+  constexpr int K = SCAN_PER_THREAD;
+  const uint32_t t = threadIdx.x, job = blockIdx.x;
   H += 2 * (size_t)job * SCAN_CHUNKS;
   G += 2 * (size_t)job * SCAN_CHUNKS;
+  auto put = [&](uint32_t i, const W& x) {
+#pragma unroll
+    for (int l = 0; l < 9; l++) lds[l * SCAN_BLOCK_THREADS + i] = x.v[l];
+  };
+  auto get = [&](uint32_t i) {
+    W x;
+#pragma unroll
+    for (int l = 0; l < 9; l++) x.v[l] = lds[l * SCAN_BLOCK_THREADS + i];
+    return x;
+  };
+  const W one = fe29_from_api(F::one());
+  const uint32_t T = (C + K - 1) / K;               // threads that hold values
   if (mode == 0) {
-    F y = c < C ? fe_load<FR>(H + 2 * c) : F::zero();
-    F wp = B.w[job];
-    for (uint32_t s = 1; s < C; s <<= 1) {
-      fe_store<FR>(lds + 2 * c, y);
+    // data scaled like the API's bytes (see above); y_c = sum_{j >= c} w^(j-c) v_j, G[c] = y_(c+1)
+    W wk[K + 1];                                    // w^0 .. w^K, true working form, normalised
+    wk[0] = one;
+    wk[1] = fe29_mul(w_from(B.w[job]), one);
+#pragma unroll
+    for (int k = 2; k <= K; k++) wk[k] = fe29_mul(wk[k - 1], wk[1]);
+    W s[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) s[k] = t * K + k < C ? fe29_unpack(fe_load<FR>(H + 2 * (t * K + k))) : W::zero();
+#pragma unroll
+    for (int k = K - 2; k >= 0; k--) s[k] = fe29_norm(fe29_add(s[k], fe29_mul(wk[1], s[k + 1])));
+    W y = s[0];                                     // the group's total, weights counted from its first chunk
+    W wp = wk[K];
+    for (uint32_t st = 1; st < T; st <<= 1) {
+      put(t, y);
       __syncthreads();
-      if (c + s < C) y = fe_add(y, fe_mul(wp, fe_load<FR>(lds + 2 * (c + s))));
+      if (t + st < T) y = fe29_norm(fe29_add(y, fe29_mul(wp, get(t + st))));
       __syncthreads();
-      wp = fe_mul(wp, wp);
+      wp = fe29_mul(wp, wp);
     }
-    fe_store<FR>(lds + 2 * c, y);
+    put(t, y);
     __syncthreads();
-    if (c < C) fe_store<FR>(G + 2 * c, c + 1 < C ? fe_load<FR>(lds + 2 * (c + 1)) : F::zero());
+    const W next = t + 1 < T ? get(t + 1) : W::zero();    // y of the following group's first chunk
+    // y_(tK+k) = s_k + w^(K-k) next; G[tK+k] = y_(tK+k+1), and G of the group's last chunk is `next`
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t c = t * K + k;
+      if (c >= C) break;
+      const W v = k + 1 < K ? fe29_add(s[k + 1], fe29_mul(wk[K - k - 1], next)) : fe29_mul(next, one);
+      fe_store<FR>(G + 2 * c, w_canonical_pack(k + 1 < K ? fe29_mul(fe29_norm(v), one) : v));
+    }
   } else {
-    F y = c < C ? fe_load<FR>(H + 2 * c) : F::one();
-    for (uint32_t s = 1; s < C; s <<= 1) {
-      fe_store<FR>(lds + 2 * c, y);
+    // G[c] = prod_{j < c} v_j
+    W p[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) p[k] = t * K + k < C ? w_load(H + 2 * (t * K + k)) : one;
+    p[0] = fe29_mul(p[0], one);
+#pragma unroll
+    for (int k = 1; k < K; k++) p[k] = fe29_mul(p[k - 1], p[k]);
+    W y = p[K - 1];
+    for (uint32_t st = 1; st < T; st <<= 1) {
+      put(t, y);
       __syncthreads();
-      if (c >= s) y = fe_mul(y, fe_load<FR>(lds + 2 * (c - s)));
+      if (t >= st) y = fe29_mul(y, get(t - st));
       __syncthreads();
     }
-    fe_store<FR>(lds + 2 * c, y);
+    put(t, y);
     __syncthreads();
-    if (c < C) fe_store<FR>(G + 2 * c, c > 0 ? fe_load<FR>(lds + 2 * (c - 1)) : F::one());
+    const W before = t > 0 ? get(t - 1) : one;      // product of every group below this one
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t c = t * K + k;
+      if (c >= C) break;
+      w_store(G + 2 * c, k == 0 ? before : fe29_mul(before, p[k - 1]));
+    }
   }
 }
 static __global__ void __launch_bounds__(64)
@@ -257,19 +413,41 @@ scan_apply_kernel(ScanBatch B, int mode, uint32_t n, uint32_t L, uint32_t C, con
   const U128* a = B.a[job];
   U128* out = B.out[job];
   const uint32_t lo = c * L, hi = min(n, lo + L);
-  F cur = fe_load<FR>(G + 2 * ((size_t)job * SCAN_CHUNKS + c));
+  const U128* g = G + 2 * ((size_t)job * SCAN_CHUNKS + c);
   if (mode == 0) {
-    const F z = B.z[job];
-    for (uint32_t i = hi; i-- > lo;) {
-      cur = fe_add(fe_mul(cur, z), fe_load<FR>(a + 2 * (size_t)i));
-      if (i >= 1) fe_store<FR>(out + 2 * (size_t)(i - 1), cur);
+    W cur = fe29_unpack(fe_load<FR>(g));
+    const W z = w_from(B.z[job]);
+    for (uint32_t top = hi; top > lo;) {
+      const uint32_t cnt = min((uint32_t)SCAN_AHEAD, top - lo);
+      F v[SCAN_AHEAD];
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) v[k] = fe_load<FR>(a + 2 * (size_t)(top - 1 - k));
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) {
+          const uint32_t i = top - 1 - k;
+          cur = fe29_add(fe29_mul(cur, z), fe29_unpack(v[k]));
+          if (i >= 1) fe_store<FR>(out + 2 * (size_t)(i - 1), w_canonical_pack(cur));
+        }
+      top -= cnt;
     }
     if (c == C - 1) fe_store<FR>(out + 2 * (size_t)(n - 1), F::zero());
   } else {
-    for (uint32_t i = lo; i < hi; i++) {
-      const F x = fe_load<FR>(a + 2 * (size_t)i);
-      fe_store<FR>(out + 2 * (size_t)i, cur);
-      cur = fe_mul(cur, x);
+    W cur = fe29_mul(w_load(g), fe29_from_api(F::one()));
+    for (uint32_t at = lo; at < hi;) {
+      const uint32_t cnt = min((uint32_t)SCAN_AHEAD, hi - at);
+      F v[SCAN_AHEAD];
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) v[k] = fe_load<FR>(a + 2 * (size_t)(at + k));
+#pragma unroll
+      for (int k = 0; k < SCAN_AHEAD; k++)
+        if ((uint32_t)k < cnt) {
+          w_store(out + 2 * (size_t)(at + k), cur);
+          cur = fe29_mul(cur, w_from(v[k]));
+        }
+      at += cnt;
     }
   }
 }
@@ -298,36 +476,6 @@ constexpr int EXPR_COLUMN_BOUND = 16, EXPR_VALUE_BOUND = 32;
 //     EXPR_VALUE_BOUND p (it multiplies by one where a sum would exceed it), so every product has operands far below
 //     the 64 p that fe29_mul and fe29_to_api allow;
 //   * the last result goes back to the API form (one product) on its way out.
-template <class FP>
-__device__ __forceinline__ Fe29<FP> expr_column_operand(const Fe<FP>& a) {
-  Fe29<FP> r;
-#pragma unroll
-  for (int j = 0; j < 9; j++) {
-    // limb j of (a << 5): bits [29 j - 5, 29 j + 24) of a
-    const int bit = 29 * j - 5;
-    uint32_t limb;
-    if (bit < 0) {
-      limb = (a.v[0] << 5) & L29_MASK;
-    } else {
-      const int w = bit >> 5, sh = bit & 31;
-      const uint64_t lo = a.v[w], hi = w + 1 < 8 ? a.v[w + 1] : 0;
-      limb = (uint32_t)((lo | (hi << 32)) >> sh) & L29_MASK;
-    }
-    // minus 16 p = (p << 4): limb j of it is bits [29 j - 4, 29 j + 25) of p
-    const int pb = 29 * j - 4;
-    uint32_t pl;
-    if (pb < 0) {
-      pl = (FP::P(0) << 4) & L29_MASK;
-    } else {
-      const int w = pb >> 5, sh = pb & 31;
-      const uint64_t lo = w < 8 ? FP::P(w) : 0, hi = w + 1 < 8 ? FP::P(w + 1) : 0;
-      pl = (uint32_t)((lo | (hi << 32)) >> sh) & L29_MASK;
-    }
-    r.v[j] = (int32_t)limb - (int32_t)pl;
-  }
-  return r;
-}
-
 // Operands that do not depend on the program's own results -- columns and constants -- are fetched TWO instructions
 // ahead (a global load is 0.5-2 us, an instruction 0.1-0.5).  LDS: 36 bytes per slot beyond the register slots and row.
 static __global__ void __launch_bounds__(EXPR_BLOCK)

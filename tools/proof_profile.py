@@ -19,7 +19,7 @@ h2lib.check(L.h2_setup(k, None, None, pbuf, cap, ctypes.byref(ln)), "h2_setup")
 params = pbuf.raw[:ln.value]
 js = ('{"x":[1,2],"output":"0x%064x"}' % prover.PoseidonCircuit([1, 2]).output()).encode()
 out = ctypes.create_string_buffer(1 << 16)
-L.h2_key_cache(0)
+L.h2_key_cache(int(os.environ.get('H2_PROFILE_KEY_CACHE', '0')))   # 0: keygen every call (as wasm.rs does)
 import time
 for i in range(N + 1):
     t = time.perf_counter()
