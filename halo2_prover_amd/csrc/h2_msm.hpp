@@ -23,8 +23,11 @@
 //    consecutive sorted entries (mixed XYZZ additions, 8M + 2S) whatever bucket they belong
 //    to, writes complete runs straight to the bucket and its cut-off head / tail runs to
 //    partial slots; a fix-up kernel sums each bucket's pieces (buckets cut into hundreds of pieces --
-//    degenerate columns -- first go through a wave-per-128-pieces reduction), then the bucket weights (b+1) and a
-//    two-level tree sum.  Fix-up, weights and tree run with FOUR LANES PER POINT (h2_curve_quad.hpp).
+//    degenerate columns -- first go through a wave-per-128-pieces reduction), then the bucket weights (b+1) by a
+//    row / column split of the bucket index (msm_rowcol_kernel, msm_final_kernel: two plain sums per bucket and a
+//    few small multiplications per column).  The whole tail runs with FOUR LANES PER POINT (h2_curve_quad.hpp).
+//  * the sort's tiles are handed out XCD by XCD (msm_tile_id): contiguous (column, tile) ranges and a counter set
+//    per XCD.
 //  * all base-field arithmetic of these kernels is done on 9 x 29-bit signed limbs with lazy reduction
 //    (h2_field29.hpp, h2_curve29.hpp); the table holds the points in that Montgomery form (R' = 2^261) and the m
 //    results are converted back to the API's form by the final kernel.
