@@ -233,6 +233,26 @@ def test_msm_resident_bases_prefix_and_batch(h2):
         bases.release()
 
 
+def test_msm_many_columns_take_the_multi_kernel_scan(h2):
+    """70 columns of 2^13 in ONE launch: 70 x 512 buckets = 35 840 keys, more than the one-block LDS scan holds, so the
+    per-XCD counters go through msm_group_fold_kernel and the three scan kernels; 512 buckets per column also give the
+    row / column weights an uneven split (32 rows x 16 columns)."""
+    curve, n, m = "pallas", 1 << 13, 70
+    b = rand_bases(curve, n)
+    bases = h2.Bases(curve, b)
+    try:
+        assert bases.plan()["window_bits"] == 10
+        cols = [rand_scalars(curve, n, seed=300 + j) for j in range(m)]
+        cols[7][:] = 0
+        cols[8][1:] = 0
+        got = bases.msm_batch(cols)
+        for j in (0, 1, 7, 8, 33, 68, 69):
+            want = norm(curve, O.best_multiexp(CID[curve], cols[j], b, threads=8))
+            assert np.array_equal(got[j], want), j
+    finally:
+        bases.release()
+
+
 def test_msm_length_mismatch_is_an_error(h2):
     with pytest.raises(ValueError):
         h2.best_multiexp(rand_scalars("bn254", 4), rand_bases("bn254", 5), "bn254")
