@@ -47,7 +47,9 @@ int h2_selftest_modmul_rate(int curve, int waves_per_simd, int iters, double* mo
  * 1: the Poseidon constants over bn256::Fr (68 x 3 round constants, MDS, inverse MDS; 32-byte canonical LE each);
  * 2 / 3 / 4: circuit 0 / 1 / 2's verifying-key digest for k = in[0] and the commitments in[1..] (64 canonical bytes
  *    x || y per fixed column then per permutation column, zero = identity) -> 32-byte transcript_repr || the Debug string;
- * 5: pairing check e(P1, Q1) e(P2, Q2) == 1 on two pairs of 64 + 128 canonical bytes -> one byte. */
+ * 5: pairing check e(P1, Q1) e(P2, Q2) == 1 on two pairs of 64 + 128 canonical bytes -> one byte;
+ * 6: the quotient program of circuit in[0] as the prover compiles it -> six u32 (instructions, products, column reads,
+ *    live-value slots, constants, inserted reductions) followed by the instructions (3 x u32 each: op_dst, a, b). */
 int h2_selftest_host(int what, const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* out_len);
 #ifdef __cplusplus
 }
