@@ -158,7 +158,8 @@ H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w,
 // stores that land in one 64-byte sector nearly all come from one XCD.  Measured (Poseidon k = 16 shape): the scatter
 // kernel 65 -> 52 us.  WRITE_SIZE did NOT fall (162 -> 152 MB for 21 MB of entries): on this chip every store
 // instruction's bytes leave the L2 as they are written (MI355X_MICROARCH.md, stores of each flavour), so a scattered
-// 4-byte store is one fabric write whatever the L2 holds -- only wider runs per store instruction would change that.
+// 4-byte store is one fabric write whatever the L2 holds -- only wider runs per store instruction change that
+// (msm_scatter_staged_kernel: 33 MB).
 // If the hardware mapped blocks differently only the locality would suffer: both kernels compute the same (group, tile).
 constexpr uint32_t MSM_XCDS = 8;
 struct MsmTileId {
@@ -186,6 +187,7 @@ inline uint32_t msm_tile_grid(uint32_t tiles, uint32_t m) {
 template <class CV>
 __global__ void __launch_bounds__(1024)
 msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ gcounts, uint32_t* __restrict__ tile_base,
+                  uint32_t* __restrict__ tile_hist /* null, or the tile's own counts for the staged scatter */,
                   uint32_t n, size_t col_stride /* elements */, uint32_t tile, uint32_t tiles, uint32_t m, MsmGeom g) {
   using S = typename CV::Scalar;
   extern __shared__ uint32_t hist[];
@@ -207,9 +209,11 @@ msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ gcoun
   // the value the atomic returns is where this tile's entries start inside the group's run: kept for the scatter
   uint32_t* tb = tile_base + ((size_t)col * tiles + id.tile) * g.B;
   uint32_t* gc = gcounts + (size_t)id.group * ((size_t)m * g.B) + (size_t)col * g.B;
+  uint32_t* th = tile_hist ? tile_hist + ((size_t)col * tiles + id.tile) * g.B : nullptr;
   for (uint32_t b = threadIdx.x; b < g.B; b += blockDim.x) {
     const uint32_t h = hist[b];
     tb[b] = h ? atomicAdd(&gc[b], h) : 0u;
+    if (th) th[b] = h;
   }
 }
 
@@ -377,6 +381,79 @@ msm_scatter_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict_
       }
     }
   }
+}
+
+// The same scatter with the tile's entries STAGED in LDS in bucket order and written out in that order: lane j of a
+// store instruction holds staged entry j, so the ~4 entries of one (tile, bucket) run -- consecutive in the bucket's
+// list -- sit in neighbouring lanes and leave as one request instead of four.  (A scattered 4-byte store is one 32-byte
+// fabric write on this chip whatever the L2 holds: 152 MB of WRITE_SIZE for 21 MB of entries with the direct kernel.)
+// LDS: cursors and (global - local) offsets per bucket, 4 + 2 bytes per staged entry; the host picks this kernel when
+// a tile with a few entries per bucket fits (msm_workspace) and the direct one otherwise (wide windows, long columns).
+template <class CV>
+__global__ void __launch_bounds__(1024)
+msm_scatter_staged_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict__ offsets,
+                          const uint32_t* __restrict__ gcounts, const uint32_t* __restrict__ tile_base,
+                          const uint32_t* __restrict__ tile_hist, uint32_t* __restrict__ sorted_ref, uint32_t n,
+                          size_t col_stride /* elements */, uint32_t n_bases, uint32_t tile, uint32_t tiles, uint32_t m,
+                          MsmGeom g, uint32_t stage_cap /* entries the staging area holds = tile * W */) {
+  using S = typename CV::Scalar;
+  extern __shared__ uint32_t hist[];
+  __shared__ uint32_t wave_sum[16];
+  __shared__ uint32_t total_s;
+  uint32_t* cur = hist;                                   // B cursors into the staging area
+  uint32_t* delta = hist + g.B;                           // B: (position in sorted_ref) - (position in the staging area)
+  uint32_t* sref = hist + 2 * (size_t)g.B;                // stage_cap entries
+  uint16_t* sbkt = reinterpret_cast<uint16_t*>(sref + stage_cap);   // their buckets
+  const MsmTileId id = msm_tile_id(tiles, m);
+  if (!id.live) return;
+  const uint32_t col = id.col;
+  const uint32_t* tb = tile_base + ((size_t)col * tiles + id.tile) * g.B;
+  const uint32_t* th = tile_hist + ((size_t)col * tiles + id.tile) * g.B;
+  const uint32_t* gc = gcounts + (size_t)col * g.B;
+  const size_t K = (size_t)m * g.B;
+  // exclusive scan of the tile's counts over the buckets: thread t owns `per` consecutive buckets
+  const uint32_t per = (g.B + blockDim.x - 1) / blockDim.x;
+  const uint32_t b_lo = min(g.B, threadIdx.x * per), b_hi = min(g.B, b_lo + per);
+  uint32_t s = 0;
+  for (uint32_t b = b_lo; b < b_hi; b++) s += th[b];
+  uint32_t incl = s;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - s;
+  for (uint32_t w = 0; w < wave; w++) run += wave_sum[w];
+  for (uint32_t b = b_lo; b < b_hi; b++) {
+    uint32_t at = offsets[(size_t)col * g.B + b] + tb[b];
+    for (uint32_t x = 0; x < id.group; x++) at += gc[x * K + b];     // the groups below this one come first in the list
+    cur[b] = run;
+    delta[b] = at - run;                                              // modulo 2^32
+    run += th[b];
+  }
+  if (threadIdx.x == blockDim.x - 1) total_s = run;
+  __syncthreads();
+  const uint32_t lo = id.tile * tile, hi = min(lo + tile, n);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    Fe<S> sc = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < g.W; w++) {
+      const uint32_t enc = msm_digit_step(sc.v, g, w, carry);
+      if (enc) {
+        const uint32_t b = (enc & ~MSM_SIGN) - 1;
+        const uint32_t pos = atomicAdd(&cur[b], 1u);
+        if (pos < stage_cap) {             // always: the counts come from the same digits (msm_digits_kernel)
+          sref[pos] = (w * n_bases + i) | (enc & MSM_SIGN);
+          sbkt[pos] = (uint16_t)b;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t total = min(total_s, stage_cap);
+  for (uint32_t j = threadIdx.x; j < total; j += blockDim.x) sorted_ref[delta[sbkt[j]] + j] = sref[j];
 }
 
 // Entries per accumulate thread, decided ON THE DEVICE from the number of entries the sort actually produced
@@ -908,9 +985,11 @@ struct MsmWorkspace {
   size_t nchunks;       // ceil(E / T)
   uint32_t log_g;       // lanes per key in the fix-up kernel = 2^log_g
   uint32_t tile;        // scalars per block in the digits / scatter kernels
+  uint32_t staged;      // the scatter stages its tile in LDS (msm_scatter_staged_kernel); stage_lds bytes of dynamic LDS
+  size_t stage_lds;
   uint32_t lb;          // low bits of a bucket index in the row / column split of the weights (msm_rowcol_kernel)
   uint32_t rc;          // row + column sums per column = 2^(log_b - lb) + 2^lb
-  size_t off_counts, off_gcounts, off_offsets, off_tile_base, off_blocksums, off_ref, off_key, off_misc, off_bsum,
+  size_t off_counts, off_gcounts, off_offsets, off_tile_base, off_tile_hist, off_blocksums, off_ref, off_key, off_misc, off_bsum,
       off_head, off_tail, off_xsum, off_rc, off_part, off_done, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
   uint32_t max_tasks;
 };
@@ -961,6 +1040,29 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   if (tile < 256) tile = 256;
   tile *= (size_t)tune_int("H2_TUNE_TILE_MUL", 2);   // measured with 1024-thread blocks (MSM_SORT_THREADS): longer runs per (tile, bucket), fewer sector writes
   if (tile > n) tile = n;
+  // the staged scatter: buckets fit 16 bits, and a tile with >= 2 entries per bucket fits the CU's LDS next to the two
+  // per-bucket arrays.  One block per CU then, so the tile is sized for a whole number of rounds of 256 blocks, as
+  // few as fit (m = 4 at 2^16: 256 blocks of 1024 scalars, 152 KB; m = 5: 512 blocks of 640).
+  ws.staged = 0;
+  ws.stage_lds = 0;
+  {
+    const size_t cap = 160 * 1024 - 512;
+    auto need = [&](size_t t) { return (size_t)8 * g.B + (size_t)6 * t * g.W + 64; };
+    if (g.B <= 65536 && n * m >= 8192 && need(dense) <= cap) {
+      for (size_t rounds = 1; rounds <= 4; rounds++) {
+        size_t t = (n * m + 256 * rounds - 1) / (256 * rounds);
+        if (t < dense) t = dense;
+        if (t < 256) t = 256;
+        if (t > n) t = n;
+        if (need(t) <= cap) {
+          tile = t;
+          ws.staged = 1;
+          ws.stage_lds = need(t);
+          break;
+        }
+      }
+    }
+  }
   ws.tile = (uint32_t)tile;
   ws.lb = (g.c - 1) / 2;
   ws.rc = (1u << (g.c - 1 - ws.lb)) + (1u << ws.lb);
@@ -970,6 +1072,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.off_gcounts = o; o = h2_align256(o + MSM_XCDS * ws.K * 4);    // per XCD group; zeroed with misc and counts
   ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
   ws.off_tile_base = o; o = h2_align256(o + ((n + ws.tile - 1) / ws.tile) * ws.K * 4);   // tiles x (m * B) words
+  ws.off_tile_hist = o; o = h2_align256(o + (ws.staged ? ((n + ws.tile - 1) / ws.tile) * ws.K * 4 : 0));
   ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
   ws.off_ref = o; o = h2_align256(o + ws.E * 4 + 16);             // + slack for the last 16-byte read
   ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
@@ -998,6 +1101,7 @@ inline hipError_t msm_kernel_setup() {
   const int lds = (int)((1u << (MSM_MAX_C - 1)) * 4);
   if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)msm_scatter_staged_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)) != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)scan_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCAN_LDS_MAX * 4));
 }
 
@@ -1036,8 +1140,9 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   const size_t lds = (size_t)g.B * 4;     // dynamic LDS limits were raised once per device by msm_kernel_setup
   const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
   const uint32_t sort_grid = msm_tile_grid(tiles, (uint32_t)m);
+  uint32_t* tile_hist = ws.staged ? (uint32_t*)(ws_base + ws.off_tile_hist) : nullptr;
   hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, gcounts,
-                     tile_base, (uint32_t)n, col_stride, ws.tile, tiles, (uint32_t)m, g);
+                     tile_base, tile_hist, (uint32_t)n, col_stride, ws.tile, tiles, (uint32_t)m, g);
   if (ws.K <= SCAN_LDS_MAX) {
     uint32_t per = (uint32_t)((ws.K + 1023) / 1024);
     per |= 1u;                                 // odd stride: the per-thread LDS walks do not collide on banks
@@ -1049,8 +1154,13 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                      ws.K);
   }
-  hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
-                     gcounts, tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles, (uint32_t)m, g);
+  if (ws.staged)
+    hipLaunchKernelGGL(msm_scatter_staged_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), ws.stage_lds, stream, d_scalars,
+                       offsets, gcounts, tile_base, tile_hist, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles,
+                       (uint32_t)m, g, (uint32_t)(ws.tile * g.W));
+  else
+    hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
+                       gcounts, tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles, (uint32_t)m, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
   const U128** d_tables = nullptr;
