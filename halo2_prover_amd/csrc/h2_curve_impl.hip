@@ -68,6 +68,16 @@ hipError_t to_affine(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s)
                      (U128*)d_out, m);
   return hipGetLastError();
 }
+hipError_t msm_small(const void* d_points, const void* d_scalars, uint32_t m, void* d_work, void* d_out_jac, hipStream_t s) {
+  const uint32_t blocks = (m + 15) / 16;
+  uint32_t* part = (uint32_t*)d_work;
+  uint32_t* counter = part + (size_t)blocks * XYZZ29_WORDS;
+  hipError_t e = hipMemsetAsync(counter, 0, 4, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(msm_small_kernel<CV>, dim3(blocks), dim3(64), 0, s, (const U128*)d_points, (const U128*)d_scalars, m, part,
+                     counter, (U128*)d_out_jac);
+  return hipGetLastError();
+}
 hipError_t points_sum(const void* d_in_jac, void* d_out_jac, uint32_t groups, uint32_t count, hipStream_t s) {
   hipLaunchKernelGGL(points_sum_kernel<CV>, dim3(count), dim3(64), 0, s, (const U128*)d_in_jac,
                      (U128*)d_out_jac, groups, count);
@@ -329,7 +339,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
   return carry ? -2 : 0;  // a carry out of the top window would lose value
 }
 
-const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, kernel_setup, table_build, msm_launch_,    srs_powers, fixed_base_mul,
+const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, kernel_setup, table_build, msm_launch_,    srs_powers, fixed_base_mul, msm_small,
                       to_jacobian, to_affine,   points_sum, ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
                       poly_pointwise, poly_inverse, poly_divide_linear, poly_prefix_product, chacha20_scalars, selftest_field, selftest_curve,
                       selftest_field_device, selftest_curve_device, selftest_digits, modmul_rate};

@@ -922,6 +922,52 @@ points_sum_kernel(const U128* __restrict__ in_jac, U128* __restrict__ out_jac, u
   }
 }
 
+// ---- a few dozen terms against points that are not an SRS (the verifier's two combinations of a proof's commitments):
+// no table, no sort -- one QUAD per term runs a 255-step double-and-add on the 4-lanes-per-point arithmetic (1.5 ms,
+// whatever m <= a few thousand is), the wave's 16 quads fold with shuffles, and the block that arrives last adds the
+// blocks' partials and writes the Jacobian result.  Registering such a vector as bases costs one inversion per window
+// and point for the table (15 ms for 30 points).  `counter` must be zero on entry (the caller's memset).
+template <class CV>
+__global__ void __launch_bounds__(64)
+msm_small_kernel(const U128* __restrict__ points /* m affine, API form */, const U128* __restrict__ scalars /* m, Montgomery */,
+                 uint32_t m, uint32_t* part /* gridDim.x points */, uint32_t* counter, U128* __restrict__ out_jac) {
+  using B = typename CV::Base;
+  using S = typename CV::Scalar;
+  const uint32_t quad = threadIdx.x >> 2, t = blockIdx.x * 16 + quad;
+  Xyzz29<CV> r = Xyzz29<CV>::identity();
+  if (t < m) {
+    const Fe<B> x = fe_load<B>(points + 4 * (size_t)t), y = fe_load<B>(points + 4 * (size_t)t + 2);
+    const Fe<S> k = fe_from_mont(fe_load<S>(scalars + 2 * (size_t)t));
+    if (!(x.is_zero() && y.is_zero())) {
+      const Xyzz29<CV> p = xyzz29_from_affine(Affine29<CV>{fe29_from_api(x), fe29_from_api(y)});
+      for (int bit = 255; bit >= 0; bit--) {
+        r = xyzz29_double_quad(r);
+        if ((k.v[bit >> 5] >> (bit & 31)) & 1) r = xyzz29_add_quad(r, p);
+      }
+    }
+  }
+  for (uint32_t d = 32; d >= 4; d >>= 1) r = xyzz_fold_down(r, d, threadIdx.x);
+  uint32_t arrived = 0;
+  if (threadIdx.x == 0) {
+    xyzz29_store<CV>(part + XYZZ29_WORDS * (size_t)blockIdx.x, r);
+    __threadfence();
+    arrived = atomicAdd(counter, 1u);
+  }
+  arrived = __shfl(arrived, 0, 64);
+  if (arrived != gridDim.x - 1) return;
+  __threadfence();
+  Xyzz29<CV> acc = Xyzz29<CV>::identity();
+  for (uint32_t b = quad; b < gridDim.x; b += 16) acc = xyzz29_add_quad(acc, xyzz29_load<CV>(part + XYZZ29_WORDS * (size_t)b));
+  for (uint32_t d = 32; d >= 4; d >>= 1) acc = xyzz_fold_down(acc, d, threadIdx.x);
+  if (threadIdx.x == 0) {
+    Fe<B> jx, jy, jz;
+    xyzz_to_jacobian(xyzz29_to_api(acc), jx, jy, jz);
+    fe_store<B>(out_jac, jx);
+    fe_store<B>(out_jac + 2, jy);
+    fe_store<B>(out_jac + 4, jz);
+  }
+}
+
 // ---- SRS generation: g[i] = [s^i] G  (ParamsKZG::new's coefficient-basis vector) -----------------
 // Device counterpart of the setup loop reached from /root/reference/circuits/src/utils.rs:59-61
 // (SURVEY.md section 3.2).  One thread per point: s^i by square-and-multiply, then a 255-step

@@ -1465,7 +1465,7 @@ struct MsmTerms {
   void add(const MsmTerms& o) { t.insert(t.end(), o.t.begin(), o.t.end()); }
 };
 
-// the group element of an MsmTerms, on the GPU: equal points merged, the rest registered as a small bases vector
+// the group element of an MsmTerms, on the GPU: equal points merged, the rest through the table-free small MSM
 G1 msm_eval(Dev& d, const MsmTerms& M) {
   std::vector<std::pair<G1, Fr>> merged;
   for (auto& st : M.t) {
@@ -1487,12 +1487,16 @@ G1 msm_eval(Dev& d, const MsmTerms& M) {
     memcpy(pts.data() + 64 * i + 32, merged[i].first.y.v.v, 32);
     memcpy(sc.data() + 32 * i, merged[i].second.v.v, 32);
   }
-  uint64_t handle = 0;
-  st_ok(h2_bases_register(H2_BN254, (const uint64_t*)pts.data(), m, &handle), "h2_bases_register");
+  // no table for points that are used once (msm_small_kernel: one quad per term)
+  const Col d_pts = (Col)d.upload(pts.data(), pts.size()), d_sc = (Col)d.upload(sc.data(), sc.size());
+  const size_t blocks = (m + 15) / 16;
+  Col work = d.col((blocks * 144 + 4 + 31) / 32), d_out = d.col(3);
+  hip_ok(ops_of(H2_BN254)->msm_small(d_pts, d_sc, (uint32_t)m, work, d_out, d.s), "msm_small");
   uint64_t jac[12];
-  const int rc = h2_msm(H2_BN254, handle, (const uint64_t*)sc.data(), m, jac);
-  (void)h2_bases_release(handle);
-  st_ok(rc, "h2_msm");
+  hip_ok(hipMemcpyAsync(jac, d_out, 96, hipMemcpyDeviceToHost, d.s), "hipMemcpyAsync(D2H)");
+  d.sync();
+  d.release(work);
+  d.release(d_out);
   const Fq X = Fq::from_mont_limbs(jac), Y = Fq::from_mont_limbs(jac + 4), Z = Fq::from_mont_limbs(jac + 8);
   if (Z.is_zero()) return out;
   const Fq zi = Z.inv(), zi2 = zi.sqr();
@@ -1510,6 +1514,7 @@ bool verify_proof(ProvingKey& K, const uint8_t* proof, size_t proof_len, const s
   const int bf = K.bf, deg = C.degree;
   if (instance.size() > n - (uint32_t)(bf + 1)) return false;
   if (!C.num_instance && !instance.empty()) return false;
+  Trace trace("verify");
   Transcript tr(proof, proof_len);
   tr.common_scalar(K.transcript_repr);
   for (auto& v : instance) tr.common_scalar(v);
@@ -1705,11 +1710,15 @@ bool verify_proof(ProvingKey& K, const uint8_t* proof, size_t proof_len, const s
     right.add(outer);
   }
   if (!bn::g2_on_curve(P.g2) || !bn::g2_on_curve(P.s_g2)) return false;
+  trace.mark("transcript replayed");
   Dev d(K.dev->c);
   const G1 L = msm_eval(d, left), Rr = msm_eval(d, right);
+  trace.mark("two MSMs");
   bn::G2 neg_g2 = P.g2;
   neg_g2.y = -neg_g2.y;
-  return bn::pairing_check({{L, P.s_g2}, {Rr, neg_g2}});
+  const bool ok = bn::pairing_check({{L, P.s_g2}, {Rr, neg_g2}});
+  trace.mark("pairing check");
+  return ok;
 }
 
 // ---- the circuits of wasm.rs by index ------------------------------------------------------------------------------------------

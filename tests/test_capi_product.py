@@ -142,6 +142,18 @@ def test_pairing_check_in_c_agrees_with_the_python_pairing(lib):
     assert host(lib, 5, enc(_g1_mul(a, (1, 2)), _G2_GEN) + enc((1, 2), neg)) == b"\x01"       # e(aG, H) e(G, -aH) = 1
     assert host(lib, 5, enc(_g1_mul(a + 1, (1, 2)), _G2_GEN) + enc((1, 2), neg)) == b"\x00"
     assert PR.pairing_check([(_g1_mul(a, (1, 2)), _G2_GEN), ((1, 2), neg)])
+    # the C side's final exponentiation is the addition chain (three powers of x), the mirror's the plain power by
+    # (p^6 + 1) / r: e(aG, bH) e(-abG, H) == 1 for more scalars, != 1 when one of them is off by one
+    rng = random.Random(5)
+    r_order = PR.R if hasattr(PR, "R") else 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    for _ in range(3):
+        x, y = rng.randrange(1, r_order), rng.randrange(1, r_order)
+        xg, yh = _g1_mul(x, (1, 2)), _g2_scalar_mul(y, _G2_GEN)
+        m = _g1_mul(x * y % r_order, (1, 2))
+        minus = (m[0], (-m[1]) % q)
+        assert host(lib, 5, enc(xg, yh) + enc(minus, _G2_GEN)) == b"\x01"
+        off = _g1_mul((x * y + 1) % r_order, (1, 2))
+        assert host(lib, 5, enc(xg, yh) + enc((off[0], (-off[1]) % q), _G2_GEN)) == b"\x00"
 
 
 def test_quotient_programs_are_well_formed_and_need_few_live_values(lib):
