@@ -159,12 +159,16 @@ static int register_device(DevCtx& src, int curve, const void* d_affine, size_t 
     if (rc != H2_OK) return fail(rc);
     uint32_t* d_bad = (uint32_t*)src.div_ws.p;
     uint32_t bad = 0;
+    // the table kernel's scratch (as large as the table) is the MSM workspace, idle while bases are being registered
+    rc = arena_acquire(src.msm_ws, be.table_bytes, src.stream);
+    if (rc != H2_OK) return fail(rc);
     hipError_t e = hipMemsetAsync(d_bad, 0, 4, src.stream);
-    if (e == hipSuccess) e = ops->table_build(d_affine, be.table[si], (uint32_t)n, g, d_bad, src.stream);
+    if (e == hipSuccess) e = ops->table_build(d_affine, be.table[si], src.msm_ws.p, (uint32_t)n, g, d_bad, src.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, src.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(src.stream);
     if (e != hipSuccess) return fail(dev_fail(e, "msm_table_kernel"));
     (void)arena_release(src.div_ws, src.stream);
+    (void)arena_release(src.msm_ws, src.stream);
     if (bad) {
       g_h2.last_error = "bases: " + std::to_string(bad) + " point(s) not on the curve";
       return fail(H2_EINVAL);

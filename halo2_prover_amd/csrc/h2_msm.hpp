@@ -98,15 +98,24 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
 // ---- table build: T[w][i] = 2^(off_w) * P_i, affine -----------------------------------------
 // `bad` counts the points that are neither the identity (0, 0) nor on the curve y^2 = x^3 + b (or whose
 // coordinates are not canonical): the reference reads its params with curve checks (SerdeFormat::RawBytes)
+//
+// One thread per point walks the 255 doublings once, in Jacobian form with a single Z (for a = 0 the XYZZ doubling
+// needs neither ZZ nor ZZZ: Z3 = Z * 2Y is all that has to be tracked), leaves (X, Y) of every window in the table slot
+// and (Z, running product of the Z so far) in `scratch`, inverts the LAST running product, and walks back dividing:
+// ONE inversion per point instead of one per window and point (20 at 2^16: they were 80 % of the kernel, 7 ms of the
+// 8 that registering 2^16 bases took; ParamsKZG::read rebuilds two such tables on every call of the reference's flow).
+// scratch: W * n * 64 bytes, laid out like the table.
 template <class CV>
 __global__ void __launch_bounds__(256)
-msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint32_t n, MsmGeom g, uint32_t* __restrict__ bad) {
+msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, U128* __restrict__ scratch, uint32_t n, MsmGeom g,
+                 uint32_t* __restrict__ bad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   using B = typename CV::Base;
+  using F = Fe<B>;
   Affine<CV> p = affine_load<CV>(bases + 4 * (size_t)i);
   if (!p.is_identity()) {
-    Fe<B> b;
+    F b;
 #pragma unroll
     for (int k = 0; k < 8; k++) b.v[k] = CV::B(k);
     uint32_t rx[8], ry[8];
@@ -120,13 +129,44 @@ msm_table_kernel(const U128* __restrict__ bases, U128* __restrict__ table, uint3
       p = Affine<CV>::identity();                       // keep the kernel's arithmetic on valid points
     }
   }
-  Xyzz<CV> cur = xyzz_from_affine(p);
+  if (p.is_identity()) {                                // every multiple of the identity is the identity
+    for (uint32_t w = 0; w < g.W; w++) affine29_store_table<CV>(table + 4 * ((size_t)w * n + i), p);
+    return;
+  }
+  F X = p.x, Y = p.y, Z = F::one(), run = F::one();
   for (uint32_t w = 0; w < g.W; w++) {
-    Affine<CV> a = (w == 0) ? p : xyzz_to_affine(cur);
-    affine29_store_table<CV>(table + 4 * ((size_t)w * n + i), a);      // working form (R' = 2^261), see h2_curve29.hpp
+    U128* slot = table + 4 * ((size_t)w * n + i);
+    U128* scr = scratch + 4 * ((size_t)w * n + i);
+    fe_store<B>(slot, X);
+    fe_store<B>(slot + 2, Y);
+    run = fe_mul(run, Z);
+    fe_store<B>(scr, Z);
+    fe_store<B>(scr + 2, run);
     if (w + 1 < g.W) {
-      for (uint32_t k = 0; k < g.width[w]; k++) cur = xyzz_double(cur);
+      for (uint32_t k = 0; k < g.width[w]; k++) {
+        // dbl-2008-s-1 (XYZZ) for a = 0, with Z instead of ZZ / ZZZ: the order of these curves is odd, Y != 0
+        const F U = fe_dbl(Y), V = fe_sqr(U), Wd = fe_mul(U, V), S = fe_mul(X, V);
+        const F xx = fe_sqr(X), M = fe_add(fe_dbl(xx), xx);
+        const F X3 = fe_sub(fe_sqr(M), fe_dbl(S));
+        Y = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(Wd, Y));
+        X = X3;
+        Z = fe_mul(Z, U);
+      }
     }
+  }
+  F inv = fe_inv(run);                                  // 1 / (Z_0 Z_1 ... Z_(W-1))
+  for (uint32_t w = g.W; w-- > 0;) {
+    U128* slot = table + 4 * ((size_t)w * n + i);
+    const U128* scr = scratch + 4 * ((size_t)w * n + i);
+    const F zw = fe_load<B>(scr);
+    F zinv = inv;                                       // w == 0: Z_0 = 1 and inv is 1 by now
+    if (w > 0) zinv = fe_mul(inv, fe_load<B>(scratch + 4 * ((size_t)(w - 1) * n + i) + 2));
+    inv = fe_mul(inv, zw);
+    const F zi2 = fe_sqr(zinv);
+    Affine<CV> a;
+    a.x = fe_mul(fe_load<B>(slot), zi2);
+    a.y = fe_mul(fe_load<B>(slot + 2), fe_mul(zi2, zinv));
+    affine29_store_table<CV>(slot, a);                  // working form (R' = 2^261), see h2_curve29.hpp
   }
 }
 

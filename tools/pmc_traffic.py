@@ -10,7 +10,7 @@ environment: bench.py reports `traffic` from it only while the sources are the o
 `step_executions` = how many times the profiled command ran the step's NTTs (warmup + steps + the 3 runs of the
 phases_ms measurement), to turn the NTT launches' total into bytes per step.
 
-Correction (MI355X_MICROARCH.md, HBM section, checked here on msm_table_kernel's known 4 MiB read): on gfx950
+Correction (MI355X_MICROARCH.md, HBM section; checked in round 1 on the then msm_table_kernel, whose only read was 4 MiB of bases): on gfx950
 FETCH_SIZE counts half the bytes of 16-byte-per-lane loads, which is what every kernel here issues, so
 traffic = 2 * FETCH_SIZE + WRITE_SIZE (both reported in KB)."""
 import collections
@@ -50,7 +50,7 @@ def main():
                       "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-proof --no-extras",
            "workload": "poseidon_k16_proof_shape, pallas", "units": "KB as reported by rocprofv3",
            "correction": "traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 halves FETCH_SIZE for 16-B-per-lane loads; "
-                         "calibrated on msm_table_kernel: n * 64 B = 4096 KB of bases read)",
+                         "calibrated in round 1 on the then msm_table_kernel: n * 64 B = 4096 KB of bases read)",
            "dominant_kernel": dict(kernels[dom], name=dom), "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
     print(dom, kernels[dom])
