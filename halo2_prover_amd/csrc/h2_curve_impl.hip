@@ -68,14 +68,24 @@ hipError_t to_affine(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s)
                      (U128*)d_out, m);
   return hipGetLastError();
 }
-hipError_t msm_small(const void* d_points, const void* d_scalars, uint32_t m, void* d_work, void* d_out_jac, hipStream_t s) {
-  const uint32_t blocks = (m + 15) / 16;
+hipError_t msm_small(const void* const* d_points, const void* const* d_scalars, const uint32_t* m, uint32_t count, void* d_work,
+                     void* d_out_jac, hipStream_t s) {
+  if (count == 0 || count > MSM_SMALL_MAX) return hipErrorInvalidValue;
+  MsmSmallBatch J{};
+  uint32_t mmax = 0;
+  for (uint32_t j = 0; j < count; j++) {
+    J.points[j] = (const U128*)d_points[j];
+    J.scalars[j] = (const U128*)d_scalars[j];
+    J.m[j] = m[j];
+    mmax = std::max(mmax, m[j]);
+  }
+  const uint32_t blocks = (mmax + 15) / 16;
+  if (blocks == 0) return hipErrorInvalidValue;
   uint32_t* part = (uint32_t*)d_work;
-  uint32_t* counter = part + (size_t)blocks * XYZZ29_WORDS;
-  hipError_t e = hipMemsetAsync(counter, 0, 4, s);
+  uint32_t* counter = part + (size_t)count * blocks * XYZZ29_WORDS;
+  hipError_t e = hipMemsetAsync(counter, 0, 4 * count, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(msm_small_kernel<CV>, dim3(blocks), dim3(64), 0, s, (const U128*)d_points, (const U128*)d_scalars, m, part,
-                     counter, (U128*)d_out_jac);
+  hipLaunchKernelGGL(msm_small_kernel<CV>, dim3(blocks, count), dim3(64), 0, s, J, part, counter, (U128*)d_out_jac);
   return hipGetLastError();
 }
 hipError_t points_sum(const void* d_in_jac, void* d_out_jac, uint32_t groups, uint32_t count, hipStream_t s) {

@@ -28,9 +28,11 @@ struct CurveOps {
                            void* d_out_jac /* optional: m Jacobian results, written by the MSM's last kernel */);
   hipError_t (*srs_powers)(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s);
   hipError_t (*fixed_base_mul)(void* d_out_affine, const void* d_scalars, uint32_t n, hipStream_t s);
-  // sum_i scalars[i] * points[i] for a few dozen arbitrary points (no table): d_work = ceil(m / 16) * 144 bytes and a
-  // 4-byte counter behind them (zeroed here); one Jacobian point out
-  hipError_t (*msm_small)(const void* d_points_affine, const void* d_scalars, uint32_t m, void* d_work, void* d_out_jac, hipStream_t s);
+  // `count` <= MSM_SMALL_MAX independent MSMs of a few dozen arbitrary points each (no table), side by side:
+  // d_work = count * (ceil(max m / 16) * 144 bytes) and count 4-byte counters behind them (zeroed here);
+  // count Jacobian points out
+  hipError_t (*msm_small)(const void* const* d_points_affine, const void* const* d_scalars, const uint32_t* m, uint32_t count,
+                          void* d_work, void* d_out_jac, hipStream_t s);
   hipError_t (*to_jacobian)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
   hipError_t (*to_affine)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
   // d_out[j] = sum_g d_in[g * count + j], Jacobian points in the API form

@@ -965,14 +965,24 @@ points_sum_kernel(const U128* __restrict__ in_jac, U128* __restrict__ out_jac, u
 // ---- a few dozen terms against points that are not an SRS (the verifier's two combinations of a proof's commitments):
 // no table, no sort -- one QUAD per term runs a 255-step double-and-add on the 4-lanes-per-point arithmetic (1.5 ms,
 // whatever m <= a few thousand is), the wave's 16 quads fold with shuffles, and the block that arrives last adds the
-// blocks' partials and writes the Jacobian result.  Registering such a vector as bases costs one inversion per window
-// and point for the table (15 ms for 30 points).  `counter` must be zero on entry (the caller's memset).
+// blocks' partials and writes the Jacobian result; grid.y = independent MSMs side by side (they are latency chains on a
+// few waves: two cost what one costs).  Registering such a vector as bases cost 15 ms for 30 points.  `counter`: zero on entry.
+constexpr uint32_t MSM_SMALL_MAX = 4;     // independent small MSMs per launch (grid.y)
+struct MsmSmallBatch {
+  const U128* points[MSM_SMALL_MAX];      // m affine points each, API form
+  const U128* scalars[MSM_SMALL_MAX];     // m scalars each, Montgomery form
+  uint32_t m[MSM_SMALL_MAX];
+};
 template <class CV>
 __global__ void __launch_bounds__(64)
-msm_small_kernel(const U128* __restrict__ points /* m affine, API form */, const U128* __restrict__ scalars /* m, Montgomery */,
-                 uint32_t m, uint32_t* part /* gridDim.x points */, uint32_t* counter, U128* __restrict__ out_jac) {
+msm_small_kernel(MsmSmallBatch J, uint32_t* part /* gridDim.y x gridDim.x points */, uint32_t* counter /* gridDim.y, zero */,
+                 U128* __restrict__ out_jac /* gridDim.y Jacobian points */) {
   using B = typename CV::Base;
   using S = typename CV::Scalar;
+  const uint32_t job = blockIdx.y, m = J.m[job];
+  const U128* points = J.points[job];
+  const U128* scalars = J.scalars[job];
+  part += XYZZ29_WORDS * (size_t)job * gridDim.x;
   const uint32_t quad = threadIdx.x >> 2, t = blockIdx.x * 16 + quad;
   Xyzz29<CV> r = Xyzz29<CV>::identity();
   if (t < m) {
@@ -991,7 +1001,7 @@ msm_small_kernel(const U128* __restrict__ points /* m affine, API form */, const
   if (threadIdx.x == 0) {
     xyzz29_store<CV>(part + XYZZ29_WORDS * (size_t)blockIdx.x, r);
     __threadfence();
-    arrived = atomicAdd(counter, 1u);
+    arrived = atomicAdd(counter + job, 1u);
   }
   arrived = __shfl(arrived, 0, 64);
   if (arrived != gridDim.x - 1) return;
@@ -1002,9 +1012,9 @@ msm_small_kernel(const U128* __restrict__ points /* m affine, API form */, const
   if (threadIdx.x == 0) {
     Fe<B> jx, jy, jz;
     xyzz_to_jacobian(xyzz29_to_api(acc), jx, jy, jz);
-    fe_store<B>(out_jac, jx);
-    fe_store<B>(out_jac + 2, jy);
-    fe_store<B>(out_jac + 4, jz);
+    fe_store<B>(out_jac + 6 * (size_t)job, jx);
+    fe_store<B>(out_jac + 6 * (size_t)job + 2, jy);
+    fe_store<B>(out_jac + 6 * (size_t)job + 4, jz);
   }
 }
 

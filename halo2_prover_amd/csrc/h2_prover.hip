@@ -1465,44 +1465,61 @@ struct MsmTerms {
   void add(const MsmTerms& o) { t.insert(t.end(), o.t.begin(), o.t.end()); }
 };
 
-// the group element of an MsmTerms, on the GPU: equal points merged, the rest through the table-free small MSM
-G1 msm_eval(Dev& d, const MsmTerms& M) {
-  std::vector<std::pair<G1, Fr>> merged;
-  for (auto& st : M.t) {
-    if (st.second.inf || st.first.is_zero()) continue;
-    bool found = false;
-    for (auto& m : merged)
-      if (m.first == st.second) {
-        m.second += st.first;
-        found = true;
-      }
-    if (!found) merged.push_back({st.second, st.first});
+// the group elements of up to four MsmTerms, on the GPU side by side: equal points merged, the rest through the table-free
+// small MSM (msm_small_kernel: one quad per term)
+std::vector<G1> msm_eval(Dev& d, const std::vector<const MsmTerms*>& jobs) {
+  const size_t count = jobs.size();
+  std::vector<G1> out(count);
+  std::vector<std::vector<uint8_t>> pts(count), sc(count);
+  std::vector<const void*> d_pts, d_sc;
+  std::vector<uint32_t> ms, live;
+  size_t mmax = 0;
+  for (size_t j = 0; j < count; j++) {
+    std::vector<std::pair<G1, Fr>> merged;
+    for (auto& st : jobs[j]->t) {
+      if (st.second.inf || st.first.is_zero()) continue;
+      bool found = false;
+      for (auto& mg : merged)
+        if (mg.first == st.second) {
+          mg.second += st.first;
+          found = true;
+        }
+      if (!found) merged.push_back({st.second, st.first});
+    }
+    if (merged.empty()) continue;
+    const size_t m = merged.size();
+    pts[j].resize(m * 64);
+    sc[j].resize(m * 32);
+    for (size_t i = 0; i < m; i++) {
+      memcpy(pts[j].data() + 64 * i, merged[i].first.x.v.v, 32);
+      memcpy(pts[j].data() + 64 * i + 32, merged[i].first.y.v.v, 32);
+      memcpy(sc[j].data() + 32 * i, merged[i].second.v.v, 32);
+    }
+    d_pts.push_back(d.upload(pts[j].data(), pts[j].size()));
+    d_sc.push_back(d.upload(sc[j].data(), sc[j].size()));
+    ms.push_back((uint32_t)m);
+    live.push_back((uint32_t)j);
+    mmax = std::max(mmax, m);
   }
-  G1 out;
-  if (merged.empty()) return out;
-  const size_t m = merged.size();
-  std::vector<uint8_t> pts(m * 64), sc(m * 32);
-  for (size_t i = 0; i < m; i++) {
-    memcpy(pts.data() + 64 * i, merged[i].first.x.v.v, 32);
-    memcpy(pts.data() + 64 * i + 32, merged[i].first.y.v.v, 32);
-    memcpy(sc.data() + 32 * i, merged[i].second.v.v, 32);
-  }
-  // no table for points that are used once (msm_small_kernel: one quad per term)
-  const Col d_pts = (Col)d.upload(pts.data(), pts.size()), d_sc = (Col)d.upload(sc.data(), sc.size());
-  const size_t blocks = (m + 15) / 16;
-  Col work = d.col((blocks * 144 + 4 + 31) / 32), d_out = d.col(3);
-  hip_ok(ops_of(H2_BN254)->msm_small(d_pts, d_sc, (uint32_t)m, work, d_out, d.s), "msm_small");
-  uint64_t jac[12];
-  hip_ok(hipMemcpyAsync(jac, d_out, 96, hipMemcpyDeviceToHost, d.s), "hipMemcpyAsync(D2H)");
+  if (live.empty()) return out;
+  const size_t blocks = (mmax + 15) / 16, nl = live.size();
+  Col work = d.col((nl * blocks * 144 + 4 * nl + 31) / 32), d_out = d.col(3 * nl);
+  hip_ok(ops_of(H2_BN254)->msm_small(d_pts.data(), d_sc.data(), ms.data(), (uint32_t)nl, work, d_out, d.s), "msm_small");
+  std::vector<uint64_t> jac(12 * nl);
+  hip_ok(hipMemcpyAsync(jac.data(), d_out, 96 * nl, hipMemcpyDeviceToHost, d.s), "hipMemcpyAsync(D2H)");
   d.sync();
   d.release(work);
   d.release(d_out);
-  const Fq X = Fq::from_mont_limbs(jac), Y = Fq::from_mont_limbs(jac + 4), Z = Fq::from_mont_limbs(jac + 8);
-  if (Z.is_zero()) return out;
-  const Fq zi = Z.inv(), zi2 = zi.sqr();
-  out.x = X * zi2;
-  out.y = Y * zi2 * zi;
-  out.inf = false;
+  for (size_t q = 0; q < nl; q++) {
+    const uint64_t* J = jac.data() + 12 * q;
+    const Fq X = Fq::from_mont_limbs(J), Y = Fq::from_mont_limbs(J + 4), Z = Fq::from_mont_limbs(J + 8);
+    if (Z.is_zero()) continue;
+    const Fq zi = Z.inv(), zi2 = zi.sqr();
+    G1& g = out[live[q]];
+    g.x = X * zi2;
+    g.y = Y * zi2 * zi;
+    g.inf = false;
+  }
   return out;
 }
 
@@ -1712,7 +1729,9 @@ bool verify_proof(ProvingKey& K, const uint8_t* proof, size_t proof_len, const s
   if (!bn::g2_on_curve(P.g2) || !bn::g2_on_curve(P.s_g2)) return false;
   trace.mark("transcript replayed");
   Dev d(K.dev->c);
-  const G1 L = msm_eval(d, left), Rr = msm_eval(d, right);
+  const std::vector<G1> lr = msm_eval(d, {&left, &right});
+  const G1& L = lr[0];
+  const G1& Rr = lr[1];
   trace.mark("two MSMs");
   bn::G2 neg_g2 = P.g2;
   neg_g2.y = -neg_g2.y;
