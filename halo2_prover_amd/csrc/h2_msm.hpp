@@ -1138,14 +1138,16 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   if (tile > n) tile = n;
   // the staged scatter: buckets fit 16 bits, and a tile with >= 2 entries per bucket fits the CU's LDS next to the two
   // per-bucket arrays.  One block per CU then, so the tile is sized for a whole number of rounds of 256 blocks, as
-  // few as fit (m = 4 at 2^16: 256 blocks of 1024 scalars, 152 KB; m = 5: 512 blocks of 640).
+  // few as fit, two at most (m = 4 at 2^16: 256 blocks of 1024 scalars, 152 KB; m = 5: 512 blocks of 640).
   ws.staged = 0;
   ws.stage_lds = 0;
   {
     const size_t cap = 160 * 1024 - 512;
     auto need = [&](size_t t) { return (size_t)8 * g.B + (size_t)6 * t * g.W + 64; };
     if (g.B <= 65536 && n * m >= 8192 && need(dense) <= cap) {
-      for (size_t rounds = 1; rounds <= 4; rounds++) {
+      // (more than two rounds of one-block-per-CU tiles cost more than the stores save: keygen's 16 sparse columns took
+      // 214 us per launch staged in four rounds against 85 us direct)
+      for (size_t rounds = 1; rounds <= 2; rounds++) {
         size_t t = (n * m + 256 * rounds - 1) / (256 * rounds);
         if (t < dense) t = dense;
         if (t < 256) t = 256;
