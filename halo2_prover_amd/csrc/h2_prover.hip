@@ -383,16 +383,18 @@ const Params& params_get(const uint8_t* bytes, size_t len) {
   if (k > 28) fail(H2_EPROOF, "params: k out of range");
   const size_t n = (size_t)1 << k;
   if (len != 4 + 128 * n + 256) fail(H2_EPROOF, "params: wrong length for k");
-  // cache key: four interleaved multiply-xorshift lanes over every byte (~10 GB/s; Blake2b took 8 ms on the 8 MiB of
-  // k = 16) finished through Blake2b -- a fingerprint against accidents, not against a caller attacking itself
-  uint64_t lane[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0xD6E8FEB86659FD93ull};
+  // cache key: eight interleaved multiply-xorshift lanes over every byte (the lanes are what keeps one core's multiplier
+  // busy: 4 lanes ran at 9 GB/s, 0.93 ms of every call at k = 16; Blake2b took 8 ms) finished through Blake2b -- a
+  // fingerprint against accidents, not against a caller attacking itself
+  uint64_t lane[8] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0xD6E8FEB86659FD93ull,
+                      0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull, 0x8EBC6AF09C88C6E3ull, 0x589965CC75374CC3ull};
   {
     const size_t words = len / 8;
     const uint8_t* q = bytes;
-    for (size_t i = 0; i + 4 <= words; i += 4, q += 32) {
-      uint64_t w[4];
-      memcpy(w, q, 32);
-      for (int l = 0; l < 4; l++) {
+    for (size_t i = 0; i + 8 <= words; i += 8, q += 64) {
+      uint64_t w[8];
+      memcpy(w, q, 64);
+      for (int l = 0; l < 8; l++) {
         lane[l] = (lane[l] ^ w[l]) * 0xFF51AFD7ED558CCDull;
         lane[l] ^= lane[l] >> 29;
       }
@@ -2023,16 +2025,21 @@ int h2_setup(uint32_t k, h2_rng_fill_t rng_fn, void* rng_ctx, uint8_t* out, size
 int h2_generate_proof(const uint8_t* params, size_t params_len, const char* json, int circuit, h2_rng_fill_t rng_fn,
                       void* rng_ctx, uint8_t* out, size_t cap, size_t* out_len) {
   return guarded([&]() -> int {
+    Trace trace("generate_proof");
     DevCtx* ctx = the_ctx();
     const Params& P = params_get(params, params_len);
+    trace.mark("params");
     const Json js(json);
     Job job = job_for_proof(js, circuit);
+    trace.mark("job");
     // the key comes from the EMPTY circuit (wasm.rs:86,95,114 rebuild it on every call; here it is kept, see
     // h2_key_cache), the witness from the JSON
     std::unique_ptr<ProvingKey> owner;
     ProvingKey& K = key_for(P, circuit, ctx, owner);
+    trace.mark("key");
     Rng rng{rng_fn, rng_ctx};
     const std::vector<uint8_t> proof = create_proof(K, *job.circuit, job.public_input, rng, job.shplonk);
+    trace.mark("create_proof");
     return emit(proof, out, cap, out_len);
   });
 }
