@@ -58,11 +58,6 @@ hipError_t fixed_base_mul(void* d_out_affine, const void* d_scalars, uint32_t n,
                      (const U128*)d_scalars, n);
   return hipGetLastError();
 }
-hipError_t to_jacobian(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
-  hipLaunchKernelGGL(msm_to_jacobian_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const uint32_t*)d_xyzz,
-                     (U128*)d_out, m);
-  return hipGetLastError();
-}
 hipError_t to_affine(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s) {
   hipLaunchKernelGGL(msm_to_affine_kernel<CV>, dim3((m + 63) / 64), dim3(64), 0, s, (const uint32_t*)d_xyzz,
                      (U128*)d_out, m);
@@ -350,7 +345,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 }
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, kernel_setup, table_build, msm_launch_,    srs_powers, fixed_base_mul, msm_small,
-                      to_jacobian, to_affine,   points_sum, ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
+                      to_affine,   points_sum, ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
                       poly_pointwise, poly_inverse, poly_divide_linear, poly_prefix_product, chacha20_scalars, selftest_field, selftest_curve,
                       selftest_field_device, selftest_curve_device, selftest_digits, modmul_rate};
 

@@ -33,7 +33,6 @@ struct CurveOps {
   // count Jacobian points out
   hipError_t (*msm_small)(const void* const* d_points_affine, const void* const* d_scalars, const uint32_t* m, uint32_t count,
                           void* d_work, void* d_out_jac, hipStream_t s);
-  hipError_t (*to_jacobian)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
   hipError_t (*to_affine)(const void* d_xyzz, void* d_out, uint32_t m, hipStream_t s);
   // d_out[j] = sum_g d_in[g * count + j], Jacobian points in the API form
   hipError_t (*points_sum)(const void* d_in_jac, void* d_out_jac, uint32_t groups, uint32_t count, hipStream_t s);

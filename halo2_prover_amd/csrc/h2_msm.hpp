@@ -898,19 +898,8 @@ static __global__ void msm_store_tables_kernel(MsmTableList L, const U128** dst,
   if (threadIdx.x < m) dst[threadIdx.x] = L.t[threadIdx.x];
 }
 
-// ---- finish: XYZZ -> Jacobian (m points) ---------------------------------------------------------
-template <class CV>
-__global__ void msm_to_jacobian_kernel(const uint32_t* __restrict__ in, U128* __restrict__ out_jac, uint32_t m) {
-  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= m) return;
-  using B = typename CV::Base;
-  const Xyzz<CV> p = xyzz29_to_api(xyzz29_load<CV>(in + XYZZ29_WORDS * (size_t)col));
-  Fe<B> x, y, z;
-  xyzz_to_jacobian(p, x, y, z);
-  fe_store<B>(out_jac + 6 * (size_t)col, x);
-  fe_store<B>(out_jac + 6 * (size_t)col + 2, y);
-  fe_store<B>(out_jac + 6 * (size_t)col + 4, z);
-}
+// ---- finish ---------------------------------------------------------------------------------------------
+// (the Jacobian result in the API's form is written by msm_final_kernel itself)
 // XYZZ -> affine (m points), for h2_msm_batch's normalised output
 template <class CV>
 __global__ void msm_to_affine_kernel(const uint32_t* __restrict__ in, U128* __restrict__ out_aff, uint32_t m) {
