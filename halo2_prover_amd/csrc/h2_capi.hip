@@ -159,8 +159,8 @@ static int register_device(DevCtx& src, int curve, const void* d_affine, size_t 
     if (rc != H2_OK) return fail(rc);
     uint32_t* d_bad = (uint32_t*)src.div_ws.p;
     uint32_t bad = 0;
-    // the table kernel's scratch (as large as the table) is the MSM workspace, idle while bases are being registered
-    rc = arena_acquire(src.msm_ws, be.table_bytes, src.stream);
+    // the table kernel's scratch (80 bytes per table entry) is the MSM workspace, idle while bases are being registered
+    rc = arena_acquire(src.msm_ws, be.table_bytes / 64 * MSM_TABLE_SCRATCH, src.stream);
     if (rc != H2_OK) return fail(rc);
     hipError_t e = hipMemsetAsync(d_bad, 0, 4, src.stream);
     if (e == hipSuccess) e = ops->table_build(d_affine, be.table[si], src.msm_ws.p, (uint32_t)n, g, d_bad, src.stream);

@@ -38,7 +38,7 @@ hipError_t kernel_setup() {
 }
 hipError_t table_build(const void* d_bases, void* d_table, void* d_scratch, uint32_t n, const MsmGeom& g, uint32_t* d_bad, hipStream_t s) {
   hipLaunchKernelGGL(msm_table_kernel<CV>, dim3((n + 255) / 256), dim3(256), 0, s, (const U128*)d_bases,
-                     (U128*)d_table, (U128*)d_scratch, n, g, d_bad);
+                     (U128*)d_table, (uint32_t*)d_scratch, n, g, d_bad);
   return hipGetLastError();
 }
 hipError_t msm_launch_(const void* d_table, const void* const* per_column, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,

@@ -20,7 +20,7 @@ struct CurveOps {
   hipError_t (*kernel_setup)();
   // MSM
   // d_bad: device counter (zeroed by the caller) of points that are not on the curve
-  // d_scratch: as many bytes as the table (W * n * 64)
+  // d_scratch: MSM_TABLE_SCRATCH (80) bytes per window and point
   hipError_t (*table_build)(const void* d_bases, void* d_table, void* d_scratch, uint32_t n, const MsmGeom& g, uint32_t* d_bad, hipStream_t s);
   hipError_t (*msm_launch)(const void* d_table, const void* const* per_column_tables, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
                            const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s,

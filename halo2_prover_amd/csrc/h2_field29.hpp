@@ -204,6 +204,43 @@ H2_HD Fe<FP> fe29_to_api(const Fe29<FP>& a) {
   return fe29_pack(t);
 }
 
+// t in (-p/2, 3p/2) with normalised limbs -> canonical, packed
+template <class FP>
+H2_HD Fe<FP> fe29_canonical_pack(Fe29<FP> t) {
+  Fe29<FP> pl;
+#pragma unroll
+  for (int i = 0; i < 9; i++) pl.v[i] = (int32_t)fe29_p<FP>(i);
+  if (t.v[8] < 0) t = fe29_norm(fe29_add(t, pl));
+  const Fe29<FP> s = fe29_norm(fe29_sub(t, pl));
+  if (s.v[8] >= 0) t = s;
+  return fe29_pack(t);
+}
+
+// a^(p-2) on the working form, two exponent bits at a time (254 squarings + ~96 products); a normalised, of small
+// magnitude (a product's result); the exponent is a constant, so the branches are uniform
+template <class FP>
+H2_HD Fe29<FP> fe29_inv(const Fe29<FP>& a) {
+  const Fe29<FP> a2 = fe29_mul(a, a), a3 = fe29_mul(a2, a);
+  uint32_t e[8];
+  uint32_t borrow = 2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {               // p - 2, with the borrow of the Pasta primes (p[0] = 1)
+    const uint32_t w = FP::P(i);
+    e[i] = w - borrow;
+    borrow = w < borrow ? 1u : 0u;
+  }
+  Fe29<FP> r = fe29_from_api(Fe<FP>::one());
+  for (int i = 254; i >= 0; i -= 2) {
+    r = fe29_mul(r, r);
+    r = fe29_mul(r, r);
+    const uint32_t d = (e[i >> 5] >> (i & 31)) & 3u;
+    if (d == 1) r = fe29_mul(r, a);
+    else if (d == 2) r = fe29_mul(r, a2);
+    else if (d == 3) r = fe29_mul(r, a3);
+  }
+  return r;
+}
+
 // x == 0 mod p for a loosely reduced x (|x| < 16 p): if x = j p then j = x[0] p^-1 mod 2^29 is tiny -- anything else
 // is rejected by that one limb; the rare survivors are reduced completely
 template <class FP>

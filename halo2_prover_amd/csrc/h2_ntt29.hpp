@@ -38,18 +38,6 @@ __global__ void __launch_bounds__(256) ntt_twiddle29_kernel(U128* tw, Fe<FP> ome
   }
 }
 
-// t in (-p/2, 3p/2) with normalised limbs -> canonical, packed
-template <class FP>
-__device__ __forceinline__ Fe<FP> fe29_canonical_pack(Fe29<FP> t) {
-  Fe29<FP> pl;
-#pragma unroll
-  for (int i = 0; i < 9; i++) pl.v[i] = (int32_t)fe29_p<FP>(i);
-  if (t.v[8] < 0) t = fe29_norm(fe29_add(t, pl));
-  const Fe29<FP> s = fe29_norm(fe29_sub(t, pl));
-  if (s.v[8] >= 0) t = s;
-  return fe29_pack(t);
-}
-
 template <class FP>
 __global__ void __launch_bounds__(1024)
 ntt29_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U128* __restrict__ tw, NttPass P,
