@@ -604,6 +604,21 @@ __device__ __forceinline__ Xyzz29<CV> xyzz_shfl_down(const Xyzz29<CV>& p, uint32
   return r;
 }
 
+// Hand-off of a block's result to the block that arrives last at a counter (msm_final_kernel, msm_small_kernel), in the
+// form MI355X_MICROARCH.md prescribes for data written by one XCD and read on another: the storing lane waits for its
+// stores, releases at agent scope, waits again (ROCm 7.2 can drop the wait behind the write-back when it believes
+// nothing is outstanding -- the count could overtake the data) and only then adds to the counter; the block that
+// sees the last count acquires before it loads.
+__device__ __forceinline__ void h2_publish_release() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void h2_consume_acquire() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // One level of a shuffle tree over quads: the lanes below `d` (of a group whose lane index is `lane`) add the point held
 // `d` lanes further up.  The other lanes keep their value: their partner lies outside the group (a lane past the end of
 // the wave reads ITSELF, and adding a point to itself sends the whole wave through the doubling path as well -- 6.2 us
@@ -887,13 +902,13 @@ msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x 8 points
       uint32_t arrived = 0;
       if (threadIdx.x == 0) {
         xyzz29_store<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + blockIdx.x), r);
-        __threadfence();                                 // the partial is visible device-wide before the count
+        h2_publish_release();                            // the partial is visible device-wide before the count
         arrived = atomicAdd(done + col, 1u);
       }
       arrived = __shfl(arrived, 0, 64);
       H2_STAMP(3);
       if (arrived != MSM_FINAL_BLOCKS - 1) return;
-      __threadfence();
+      h2_consume_acquire();
       // quads 0-3: row-family partials, quads 4-7: column-family partials
       r = P::identity();
       if (quad < MSM_FINAL_BLOCKS) r = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + quad));
@@ -1015,12 +1030,12 @@ msm_small_kernel(MsmSmallBatch J, uint32_t* part /* gridDim.y x gridDim.x points
   uint32_t arrived = 0;
   if (threadIdx.x == 0) {
     xyzz29_store<CV>(part + XYZZ29_WORDS * (size_t)blockIdx.x, r);
-    __threadfence();
+    h2_publish_release();
     arrived = atomicAdd(counter + job, 1u);
   }
   arrived = __shfl(arrived, 0, 64);
   if (arrived != gridDim.x - 1) return;
-  __threadfence();
+  h2_consume_acquire();
   Xyzz29<CV> acc = Xyzz29<CV>::identity();
   for (uint32_t b = quad; b < gridDim.x; b += 16) acc = xyzz29_add_quad(acc, xyzz29_load<CV>(part + XYZZ29_WORDS * (size_t)b));
   for (uint32_t d = 32; d >= 4; d >>= 1) acc = xyzz_fold_down(acc, d, threadIdx.x);
