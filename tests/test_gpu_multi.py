@@ -192,6 +192,41 @@ def test_two_streams_at_once_give_the_one_stream_results(h2):
         bases.release()
 
 
+def test_last_block_handoff_under_uneven_load(h2):
+    """msm_final_kernel hands eight blocks' partials to the block that arrives last (counter + agent release / acquire).
+    150 launches of the same MSM while another stream keeps every CU busy with multi-pass NTTs: every result must be the
+    first one's point (a stale partial would show as a different point)."""
+    import torch
+    curve, n, m = "pallas", 1 << 14, 5
+    cid = O.CURVE_IDS[curve]
+    b = O.synth_bases(cid, SEED | 0xC15, n).reshape(n, 8)
+    bases = h2.Bases(curve, b)
+    try:
+        cols = np.stack([O.synth_scalars(O.CURVE_SCALAR_FIELD[cid], SEED | (0xC40 + j), n).reshape(n, 4) for j in range(m)])
+        dev = torch.from_numpy(cols.view(np.int64)).cuda()
+        lg = 19
+        dbig = torch.from_numpy(O.synth_scalars(O.CURVE_SCALAR_FIELD[cid], SEED | 0xC99, 3 << lg).reshape(3 << lg, 4).view(np.int64)).cuda()
+        w = _omega(curve, lg)
+        rounds = 150
+        outs = torch.zeros((rounds, m, 12), dtype=torch.int64, device="cuda")
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for r in range(rounds):
+            if r % 3 == 0:
+                h2.ntt_device(dbig.data_ptr(), 3, w, lg, curve, sb.cuda_stream)
+            bases.msm_device(dev.data_ptr(), n, m, outs[r].data_ptr(), sa.cuda_stream)
+        torch.cuda.synchronize()
+        res = outs.cpu().numpy().view(np.uint64)
+        want = [O.to_affine(cid, res[0][j]) for j in range(m)]
+        for j in range(m):
+            assert np.array_equal(want[j], O.to_affine(cid, O.best_multiexp(cid, cols[j], b, threads=8))), j
+        for r in range(1, rounds):
+            for j in range(m):
+                assert np.array_equal(O.to_affine(cid, res[r][j]), want[j]), (r, j)
+    finally:
+        bases.release()
+
+
 def test_generate_params_on_a_side_stream_reproduces_the_pinned_file(h2):
     """the library calls of generate_params follow torch's CURRENT stream (their inputs are made there)"""
     import hashlib
