@@ -259,6 +259,10 @@ struct Dev {
     if (scale) limbs(*scale, sc);
     st_ok(ntt_enqueue(*c, H2_BN254, a, m, w, log_n, on ? on : s, scale ? sc : nullptr), "ntt_enqueue");
   }
+  // `on` waits for the accumulate kernel of the MSM enqueued last on this context (commit_begin)
+  void wait_msm_tail(hipStream_t on) {
+    if (c->tail_recorded && c->tail_event) hip_ok(hipStreamWaitEvent(on, c->tail_event, 0), "hipStreamWaitEvent(tail)");
+  }
   // the second stream of this context (non-blocking) and three events to hand work back and forth
   hipStream_t side() {
     if (!c->side_stream) {
@@ -702,24 +706,8 @@ HX hx_mul(const Fr& k, const HX& p) {
 
 // `split` < m: columns [0, split) commit against g_lagrange and [split, m) against g IN THE SAME LAUNCH (commitments
 // that do not wait for each other: the permutation products and the RNG-drawn random polynomial)
-std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange, size_t split = ~(size_t)0) {
-  auto it = g_h2.bases.find(lagrange ? P.h_gl : P.h_g);
-  if (it == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
-  void* out = d.alloc(m * 96);
-  if (split < m) {
-    auto ig = g_h2.bases.find(P.h_g), il = g_h2.bases.find(P.h_gl);
-    if (ig == g_h2.bases.end() || il == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
-    std::vector<const BasesEntry*> per(m);
-    for (size_t j = 0; j < m; j++) per[j] = j < split ? &il->second : &ig->second;
-    st_ok(msm_device_run(*d.c, H2_BN254, il->second, cols, 0, n, n, m, out, false, d.s, per.data()), "msm_device_run");
-  } else {
-    st_ok(msm_device_run(*d.c, H2_BN254, it->second, cols, 0, n, n, m, out, false, d.s), "msm_device_run");
-  }
-  std::vector<uint8_t> raw(m * 96);
-  hip_ok(hipMemcpyAsync(raw.data(), out, raw.size(), hipMemcpyDeviceToHost, d.s), "hipMemcpyAsync(D2H)");
-  d.sync();
-  d.release(out);
-  // Jacobian -> affine on the host: m inversions folded into one (a one-thread device kernel took 0.35 ms per phase)
+// Jacobian -> affine on the host: m inversions folded into one (a one-thread device kernel took 0.35 ms per phase)
+std::vector<G1> jacobian_to_affine_host(const std::vector<uint8_t>& raw, size_t m) {
   std::vector<Fq> zs(m), pre(m);
   Fq acc = Fq::one();
   for (size_t j = 0; j < m; j++) {
@@ -738,6 +726,45 @@ std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, 
     pts[j].inf = false;
   }
   return pts;
+}
+
+// The MSM of a commit phase is enqueued by commit_begin and read back by commit_finish: what is queued between the two
+// on the second stream behind Dev::wait_msm_tail starts when the accumulate kernel of that MSM has finished, i.e. runs
+// beside the MSM's small-grid tail instead of competing with its sort and accumulate kernels (started at once, the
+// advice transforms made the sort kernels of the advice commitment three times slower: 140 against 48 us).
+struct PendingCommit {
+  void* out = nullptr;
+  size_t m = 0;
+};
+PendingCommit commit_begin(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange, size_t split = ~(size_t)0) {
+  auto it = g_h2.bases.find(lagrange ? P.h_gl : P.h_g);
+  if (it == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
+  PendingCommit pc;
+  pc.m = m;
+  pc.out = d.alloc(m * 96);
+  d.c->tail_wanted = true;                   // the MSM records an event behind its accumulate kernel (Dev::wait_msm_tail)
+  if (split < m) {
+    auto ig = g_h2.bases.find(P.h_g), il = g_h2.bases.find(P.h_gl);
+    if (ig == g_h2.bases.end() || il == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
+    std::vector<const BasesEntry*> per(m);
+    for (size_t j = 0; j < m; j++) per[j] = j < split ? &il->second : &ig->second;
+    st_ok(msm_device_run(*d.c, H2_BN254, il->second, cols, 0, n, n, m, pc.out, false, d.s, per.data()), "msm_device_run");
+  } else {
+    st_ok(msm_device_run(*d.c, H2_BN254, it->second, cols, 0, n, n, m, pc.out, false, d.s), "msm_device_run");
+  }
+  return pc;
+}
+std::vector<G1> commit_finish(Dev& d, PendingCommit& pc) {
+  std::vector<uint8_t> raw(pc.m * 96);
+  hip_ok(hipMemcpyAsync(raw.data(), pc.out, raw.size(), hipMemcpyDeviceToHost, d.s), "hipMemcpyAsync(D2H)");
+  d.sync();
+  d.release(pc.out);
+  pc.out = nullptr;
+  return jacobian_to_affine_host(raw, pc.m);
+}
+std::vector<G1> commit(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange, size_t split = ~(size_t)0) {
+  PendingCommit pc = commit_begin(d, P, cols, n, m, lagrange, split);
+  return commit_finish(d, pc);
 }
 
 // coeff (m columns of n, stride n) -> extended-coset evaluations (m columns of en)
@@ -1058,11 +1085,14 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
   Col polys = d.col((na + ni + nz) * (size_t)n);
   Col ext = d.col((na + ni + nz) * (size_t)en);
   hipStream_t side = d.side();
-  d.order(d.s, side, 0);
-  hip_ok(hipMemcpyAsync(polys, lag, (na + ni) * (size_t)n * 32, hipMemcpyDeviceToDevice, side), "hipMemcpyAsync(D2D)");
-  d.ntt(polys, na + ni, D.omega_inv, D.k, &D.n_inv, side);
-  coeff_to_extended(d, D, polys, na + ni, ext, side);
-  for (auto& pt : commit(d, P, advice_values, n, na, true)) tr.write_point(pt);
+  {
+    PendingCommit pc = commit_begin(d, P, advice_values, n, na, true);
+    d.wait_msm_tail(side);                     // (the tail event lies behind the witness upload on the main stream)
+    hip_ok(hipMemcpyAsync(polys, lag, (na + ni) * (size_t)n * 32, hipMemcpyDeviceToDevice, side), "hipMemcpyAsync(D2D)");
+    d.ntt(polys, na + ni, D.omega_inv, D.k, &D.n_inv, side);
+    coeff_to_extended(d, D, polys, na + ni, ext, side);
+    for (auto& pt : commit_finish(d, pc)) tr.write_point(pt);
+  }
   trace.mark("advice committed");
   const Fr theta = tr.squeeze_challenge(), beta = tr.squeeze_challenge(), gamma = tr.squeeze_challenge();
   (void)theta;
@@ -1139,14 +1169,17 @@ std::vector<uint8_t> create_proof(ProvingKey& K, const Circuit& C, const std::ve
     hip_ok(d.ops->chacha20_scalars(random_poly, n, 0, key, d.s), "chacha20_scalars");
     (void)rng.fr_random();
   }
-  if (nz) {
-    d.order(d.s, side, 1);                     // the z columns (blinding rows included) are final on the main stream
-    Col zp = polys + 2 * (na + ni) * (size_t)n;
-    hip_ok(hipMemcpyAsync(zp, z_values, nz * (size_t)n * 32, hipMemcpyDeviceToDevice, side), "hipMemcpyAsync(D2D)");
-    d.ntt(zp, nz, D.omega_inv, D.k, &D.n_inv, side);
-    coeff_to_extended(d, D, zp, nz, ext + 2 * (na + ni) * (size_t)en, side);
+  {
+    PendingCommit pc = commit_begin(d, P, z_values, n, nz + 1, true, nz);
+    if (nz) {
+      d.wait_msm_tail(side);                   // the z columns (blinding rows included) are final before that MSM
+      Col zp = polys + 2 * (na + ni) * (size_t)n;
+      hip_ok(hipMemcpyAsync(zp, z_values, nz * (size_t)n * 32, hipMemcpyDeviceToDevice, side), "hipMemcpyAsync(D2D)");
+      d.ntt(zp, nz, D.omega_inv, D.k, &D.n_inv, side);
+      coeff_to_extended(d, D, zp, nz, ext + 2 * (na + ni) * (size_t)en, side);
+    }
+    for (auto& pt : commit_finish(d, pc)) tr.write_point(pt);
   }
-  for (auto& pt : commit(d, P, z_values, n, nz + 1, true, nz)) tr.write_point(pt);
   trace.mark("grand products + random poly committed");
 
   Col advice_polys = polys, z_polys = polys + 2 * (na + ni) * (size_t)n;
