@@ -200,6 +200,11 @@ int msm_common_checks(int curve, uint64_t handle, size_t first, size_t n, size_t
 // Columns per launch: the sort indexes its m * W * n entries with 32 bits, so a wide batch of long columns
 // (2^24 rows x 8 columns) goes through in groups of columns, one after the other on the same stream and workspace.
 static uint64_t g_msm_max_entries = (1ull << 31) - 1;   // lowered only by h2_selftest_set_msm_max_entries (tests)
+// guard mode (tests only, h2_selftest_msm_guard): the workspace is laid out with a red zone behind every region, filled
+// with a pattern before each launch sequence and inspected after it
+static bool g_msm_guard = false, g_msm_guard_poke = false;
+static uint64_t g_guard_launches = 0, g_guard_violations = 0;
+static std::string g_guard_first;
 static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
   const uint64_t per_col = (uint64_t)be.geom.W * n;
   const uint64_t by_entries = g_msm_max_entries / per_col;
@@ -227,10 +232,16 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
   const char* table = (const char*)be.table[ctx_index(&c)] + first_base * 64;
   for (size_t j0 = 0; j0 < m; j0 += group) {
     const size_t mm = m - j0 < group ? m - j0 : group;
-    MsmWorkspace ws = msm_workspace(n, mm, be.geom);
+    MsmWorkspace ws = msm_workspace(n, mm, be.geom, g_msm_guard ? 256u : 0u);
     if (ws.E >= (1ull << 31) || ws.K >= (1ull << 31)) return H2_EINVAL;
     int rc = arena_acquire(c.msm_ws, ws.total, stream);
     if (rc != H2_OK) return rc;
+    // every kernel's index range against the region it indexes, before anything is enqueued
+    if (const char* broken = msm_check(ws, be.geom, n, mm, col_stride, (uint32_t)(be.n - first_base), c.msm_ws.bytes)) {
+      g_h2.last_error = std::string("msm launch geometry: ") + broken;
+      return H2_EDEVICE;
+    }
+    if (g_msm_guard) H2_TRY(hipMemsetAsync(c.msm_ws.p, MSM_GUARD_BYTE, ws.total, stream));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_h2.profiling) {
       if (c.prof_used == c.prof_events.size()) {
@@ -252,6 +263,26 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
                                    affine_out ? nullptr : dst);
     c.tail_recorded = c.tail_wanted;
     if (e != hipSuccess) return dev_fail(e, "msm_launch");
+    if (g_msm_guard) {
+      uint32_t* d_bad = nullptr;
+      std::vector<uint32_t> bad(ws.n_regions, 0);
+      H2_TRY(hipMalloc(&d_bad, ws.n_regions * 4));
+      H2_TRY(hipMemsetAsync(d_bad, 0, ws.n_regions * 4, stream));
+      if (g_msm_guard_poke)        // the checker's own test: one byte just behind the second region
+        H2_TRY(hipMemsetAsync((char*)c.msm_ws.p + ws.regions[1].off + ws.regions[1].bytes, 0, 1, stream));
+      hipLaunchKernelGGL(msm_guard_check_kernel, dim3(ws.n_regions), dim3(256), 0, stream, (const uint8_t*)c.msm_ws.p, ws, d_bad);
+      H2_TRY(hipMemcpyAsync(bad.data(), d_bad, ws.n_regions * 4, hipMemcpyDeviceToHost, stream));
+      H2_TRY(hipStreamSynchronize(stream));
+      (void)hipFree(d_bad);
+      g_guard_launches++;
+      for (uint32_t r = 0; r < ws.n_regions; r++)
+        if (bad[r]) {
+          if (!g_guard_violations)
+            g_guard_first = std::string(ws.regions[r].name) + ": " + std::to_string(bad[r]) + " byte(s) behind the region, n=" +
+                            std::to_string(n) + " m=" + std::to_string(mm) + (ws.sort2 ? " two-level sort" : ws.staged ? " staged scatter" : " direct scatter");
+          g_guard_violations++;
+        }
+    }
     if (affine_out) {
       e = ops->to_affine((char*)c.msm_ws.p + ws.off_tree2, dst, (uint32_t)mm, stream);
       if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
@@ -947,6 +978,61 @@ extern "C" int h2_selftest_field_op_device(int field, int op, const uint64_t* a,
   H2_TRY(hipMemcpyAsync(out, d + 2 * n * 32, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
   H2_TRY(hipStreamSynchronize(g_ctx.stream));
   return H2_OK;
+}
+
+// test hooks around the MSM workspace (include/h2hip_selftest.h)
+extern "C" int h2_selftest_msm_guard(int on) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  h2::g_msm_guard = on != 0;
+  h2::g_msm_guard_poke = on == 2;
+  h2::g_guard_launches = h2::g_guard_violations = 0;
+  h2::g_guard_first.clear();
+  return H2_OK;
+}
+extern "C" int h2_selftest_msm_guard_report(uint64_t out[2], char* first, size_t cap) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!out) return H2_EINVAL;
+  out[0] = h2::g_guard_launches;
+  out[1] = h2::g_guard_violations;
+  if (first && cap) {
+    snprintf(first, cap, "%s", h2::g_guard_first.c_str());
+  }
+  return H2_OK;
+}
+// host only: lay out the workspace of an (n_bases, n, m, col_stride) launch as msm_device_run would and run the bounds
+// proof on it; out[0..7] = window bits, windows, buckets, tile, staged, two-level sort, entries per thread, regions.
+// Returns H2_OK, or H2_EINVAL with the violated condition in h2_last_device_error().
+extern "C" int h2_selftest_msm_check(int curve, size_t n_bases, size_t n, size_t m, size_t col_stride, int guard, uint64_t out[8]) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  const CurveOps* ops = ops_of(curve);
+  if (!ops || n == 0 || m == 0 || n > n_bases) return H2_EINVAL;
+  const MsmGeom g = msm_geometry(n_bases, ops->scalar_bits);
+  const MsmWorkspace ws = msm_workspace(n, m, g, guard ? 256u : 0u);
+  if (out) {
+    out[0] = g.c; out[1] = g.W; out[2] = g.B; out[3] = ws.sort2 ? ws.s2.tile : ws.tile;
+    out[4] = ws.staged; out[5] = ws.sort2; out[6] = ws.T; out[7] = ws.n_regions;
+  }
+  if (const char* broken = msm_check(ws, g, n, m, col_stride, (uint32_t)n_bases, ws.total)) {
+    g_h2.last_error = std::string("msm launch geometry: ") + broken;
+    return H2_EINVAL;
+  }
+  return H2_OK;
+}
+// host only: the sort's block -> (column, tile) mapping for `tiles` tiles per column and m columns: every block of
+// the grid is either dead or maps to a (column < m, tile < tiles) pair that no other block takes, and all pairs are taken
+extern "C" int h2_selftest_msm_tiles(uint32_t tiles, uint32_t m) {
+  if (tiles == 0 || m == 0 || (uint64_t)tiles * m > (1u << 24)) return H2_EINVAL;
+  const uint32_t grid = msm_tile_grid(tiles, m);
+  std::vector<uint8_t> seen((size_t)tiles * m, 0);
+  size_t live = 0;
+  for (uint32_t b = 0; b < grid; b++) {
+    const MsmTileId t = msm_tile_id_of(b, tiles, m);
+    if (!t.live) continue;
+    if (t.col >= m || t.tile >= tiles || t.group >= MSM_XCDS || seen[(size_t)t.col * tiles + t.tile]) return H2_EINVAL;
+    seen[(size_t)t.col * tiles + t.tile] = 1;
+    live++;
+  }
+  return live == (size_t)tiles * m ? H2_OK : H2_EINVAL;
 }
 
 // test hook: lower the sort's entry limit so that the grouped-columns path is reached at small sizes (0 = default)

@@ -232,20 +232,30 @@ struct MsmTileId {
   uint32_t group, col, tile;
   bool live;
 };
-__device__ __forceinline__ MsmTileId msm_tile_id(uint32_t tiles, uint32_t m) {
+// (a function of the block index alone, so that the host can check the mapping: h2_selftest_msm_tiles)
+H2_HD MsmTileId msm_tile_id_of(uint32_t block, uint32_t tiles, uint32_t m) {
   const uint32_t total = tiles * m, per = (total + MSM_XCDS - 1) / MSM_XCDS;
   MsmTileId t;
-  t.group = blockIdx.x % MSM_XCDS;
-  const uint32_t v = t.group * per + blockIdx.x / MSM_XCDS;
-  t.live = blockIdx.x / MSM_XCDS < per && v < total;
+  t.group = block % MSM_XCDS;
+  const uint32_t v = t.group * per + block / MSM_XCDS;
+  // the grid is rounded up to a multiple of 8 blocks: the surplus blocks of the last groups are dead.  Without the
+  // `v < total` test such a block would take (column, tile) = (v / tiles >= m, ...) and read scalars past the last
+  // column (the memory-access fault recorded in round 2)
+  t.live = block / MSM_XCDS < per && v < total;
   t.col = v / tiles;
   t.tile = v % tiles;
   return t;
 }
+__device__ __forceinline__ MsmTileId msm_tile_id(uint32_t tiles, uint32_t m) { return msm_tile_id_of(blockIdx.x, tiles, m); }
 inline uint32_t msm_tile_grid(uint32_t tiles, uint32_t m) {
   return (tiles * m + MSM_XCDS - 1) / MSM_XCDS * MSM_XCDS;
 }
 
+}  // namespace h2
+#include "h2_msm_sort2.hpp"
+namespace h2 {
+
+// ---- the one-level sort (short columns: B <= 4096 buckets per column) ------------------------------------------------
 // Count pass: every scalar's signed digits (0 or |d| | sign<<31) go into an LDS histogram of the tile;
 // gcounts[group][col*B + |d|-1] += the tile's count with one RETURNING global atomic per non-empty bucket, whose
 // result -- where this tile's entries start inside the group's part of the bucket's list -- is kept in tile_base.
@@ -768,13 +778,17 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host
 // (msm_final_kernel).  Before: one 12-bit double-and-add per bucket (12 doublings + ~6 additions, 75 us per launch at
 // the proof shape -- VALU-bound, 16 384 quads on 1024 SIMDs) and a two-level tree behind it (2 x 42 us).
 //
-// One wave per row or column sum: 16 quads (4 lanes per point, h2_curve_quad.hpp) fold the points quad, quad + 16, ...
-// and a 4-level shuffle tree joins them.
+// One block of 1, 2 or 4 waves per row or column sum: the quads (4 lanes per point, h2_curve_quad.hpp) fold the points
+// quad, quad + nq, ..., a 4-level shuffle tree joins a wave's 16 quads, the waves' sums meet in LDS.  The factor 2^lb of
+// the row family is applied HERE, by lb doublings of every row sum (and of the last column's sum, whose multiplier
+// cols = 2^lb * 1 is the one that does not fit lb bits): the row waves have fewer points to add than the column waves
+// when hb > lb, and a doubling done by 2^hb waves side by side is off the final kernel's one chain.
 template <class CV>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, uint32_t* __restrict__ done,
                   uint32_t log_b, uint32_t lb) {
   __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
+  __shared__ uint32_t xw[3][XYZZ29_WORDS];
   const uint32_t col = blockIdx.y;
   if (blockIdx.x == 0 && threadIdx.x == 0) done[col] = 0;       // msm_final_kernel's arrival counter
   const uint32_t rows = 1u << (log_b - lb), cols = 1u << lb;
@@ -782,13 +796,32 @@ msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, 
   const uint32_t first = is_row ? blockIdx.x * cols : blockIdx.x - rows;
   const uint32_t stride = is_row ? 1u : cols, len = is_row ? cols : rows;
   const uint32_t* base = xsum + XYZZ29_WORDS * ((size_t)col << log_b);
-  const uint32_t quad = threadIdx.x >> 2;
+  const uint32_t quad = threadIdx.x >> 2, nq = blockDim.x >> 2, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // the first point is taken as it is: an addition onto the identity costs as much as any other
   Xyzz29<CV> a = quad < len ? xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + quad * stride)) : Xyzz29<CV>::identity();
-  for (uint32_t j = quad + 16; j < len; j += 16)
+  for (uint32_t j = quad + nq; j < len; j += nq)
     a = xyzz29_add_quad(a, xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + j * stride)));
-  for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_fold_down(a, d, threadIdx.x);
+  for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_fold_down(a, d, lane);
+  if (blockDim.x > 64) {
+    if (wave > 0 && lane == 0) xyzz29_store<CV>(xw[wave - 1], a);
+    __syncthreads();
+    if (wave > 0) return;
+    const uint32_t nw = blockDim.x >> 6;
+    if (quad >= 1) a = quad < nw ? xyzz29_load<CV>(xw[quad - 1]) : Xyzz29<CV>::identity();
+    for (uint32_t d = 2 * nw; d >= 4; d >>= 1) a = xyzz_fold_down(a, d, lane);
+  }
+  if (is_row || blockIdx.x == rows + cols - 1)
+    for (uint32_t k = 0; k < lb; k++) a = xyzz29_double_quad(a);
   if (threadIdx.x == 0) xyzz29_store<CV>(rc + XYZZ29_WORDS * ((size_t)col * (rows + cols) + blockIdx.x), a);
+}
+// waves per row / column sum: as many as shorten the chains (a wave wants >= 2 points per quad) while the launch stays
+// at about one wave per SIMD -- two of these chains on one SIMD run at half speed each
+inline uint32_t msm_rowcol_waves(uint32_t log_b, uint32_t lb, size_t m) {
+  const uint32_t rows = 1u << (log_b - lb), cols = 1u << lb;
+  const uint32_t shortest = rows < cols ? rows : cols;
+  uint32_t nw = 1;
+  while (nw < 4 && shortest >= 64 * nw && (size_t)(rows + cols) * m * (2 * nw) <= 1024) nw *= 2;
+  return nw;
 }
 
 // word-wise choice among three points by a per-quad digit (0 -> the identity, which is all zeros)
@@ -806,112 +839,98 @@ __device__ __forceinline__ Xyzz29<CV> xyzz29_pick(uint32_t dig, const Xyzz29<CV>
   return r;
 }
 
-// Eight one-wave blocks per column, each on a SIMD of its own (two waves sharing a SIMD run these chains at half
-// speed: the 4-lanes-per-point arithmetic keeps a SIMD's issue port busy with ONE wave).  Blocks 0-3 weigh the row
-// family, blocks 4-7 the column family, 16 items per wave and round:
-//     row family     item 0 = C_(cols-1) with multiplier 1 (its own multiplier 2^lb = 2^lb * 1 joins the rows, whose
-//                    item 0 would have multiplier 0), item hi = R_hi with multiplier hi            (< 2^hb)
-//     column family  item lo = C_lo with multiplier lo + 1, lo < cols - 1                           (< 2^lb)
+// One-wave blocks, each on a SIMD of its own (two waves sharing a SIMD run these chains at half speed: the
+// 4-lanes-per-point arithmetic keeps a SIMD's issue port busy with ONE wave), ONE item per quad, so the chain is as
+// long as one multiplication whatever the bucket count (with a fixed eight blocks a 2^20-term MSM -- 256 + 127 items --
+// went round four times: 205 us):
+//     row family     blocks [0, ceil(rows / 16)):   item 0 = the last column's sum with multiplier 1 (rc holds it times
+//                    2^lb: its multiplier cols = 2^lb * 1; the rows' own item 0 would have multiplier 0),
+//                    item hi = 2^lb R_hi with multiplier hi                                    (< 2^hb)
+//     column family  the blocks behind them:        item lo = C_lo with multiplier lo + 1, lo < cols - 1   (< 2^lb)
 // multiplied two bits at a time (x, 2x, 3x, then per digit two doublings and one addition of the quad's own choice),
 // a shuffle tree over the wave's 16 quads, and the block that arrives last (a counter per column, zeroed by
-// msm_rowcol_kernel) adds the eight partials, doubles the row family lb times and writes the column's MSM: XYZZ on the
+// msm_rowcol_kernel) adds the blocks' partials (two per quad, one more tree) and writes the column's MSM: XYZZ on the
 // working form to out[col] and, when out_jac is given, the Jacobian point in the API's form.
 //
 // The whole chain is ONE loop around one doubling and one addition (a little program counter decides what each step
 // does): written as straight-line code the kernel was 180 KB -- every inlined addition is ~24 KB -- and each copy ran
 // exactly once, from a cold instruction cache (4.9 us against 3.6 us for an addition; tools/microbench_tail.hip).
-constexpr uint32_t MSM_FINAL_BLOCKS = 8;
+constexpr uint32_t MSM_FINAL_MAX_BLOCKS = 32;
+H2_HD uint32_t msm_final_row_blocks(uint32_t log_b, uint32_t lb) { return ((1u << (log_b - lb)) + 15u) / 16u; }
+H2_HD uint32_t msm_final_blocks(uint32_t log_b, uint32_t lb) {
+  return msm_final_row_blocks(log_b, lb) + ((1u << lb) - 1u + 15u) / 16u;
+}
 template <class CV>
 __global__ void __launch_bounds__(64)
-msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x 8 points */, uint32_t* done,
+msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x MSM_FINAL_MAX_BLOCKS points */, uint32_t* done,
                  uint32_t* __restrict__ out, U128* __restrict__ out_jac, uint32_t log_b, uint32_t lb) {
   __builtin_amdgcn_s_setprio(3);
   using P = Xyzz29<CV>;
   const uint32_t col = blockIdx.y;
   const uint32_t hb = log_b - lb, rows = 1u << hb, cols = 1u << lb;
-  const uint32_t fam = blockIdx.x >> 2, lane = threadIdx.x, quad = threadIdx.x >> 2;
+  const uint32_t nb_row = msm_final_row_blocks(log_b, lb), nb = gridDim.x;
+  const uint32_t fam = blockIdx.x >= nb_row ? 1u : 0u, lane = threadIdx.x, quad = threadIdx.x >> 2;
   const uint32_t cnt = fam ? cols - 1 : rows;
-  const uint32_t ndig = ((fam ? lb : hb) + 1) >> 1;              // base-4 digits of the family's multipliers
+  const uint32_t ndig = max(1u, ((fam ? lb : hb) + 1) >> 1);     // base-4 digits of the family's multipliers
   const uint32_t* src = rc + XYZZ29_WORDS * ((size_t)col * (rows + cols));
-  const uint32_t first = (blockIdx.x & 3u) * 16;
-  const uint32_t n_items = first < cnt ? (cnt - first + 63) / 64 : 0;   // the same for the whole wave
-  const uint32_t per_item = 3 * ndig;                            // double, add x, (double, double, add)*, add acc
-  const uint32_t n_weigh = n_items * per_item, n_tree = n_weigh + 4, n_all = n_tree + 3 + lb;
-  P r = P::identity(), x = P::identity(), x2 = P::identity(), x3 = P::identity();
-  P acc = P::identity(), keep = P::identity();
+  const uint32_t i = (fam ? blockIdx.x - nb_row : blockIdx.x) * 16 + quad;   // this quad's item
+  const uint32_t n_weigh = 3 * ndig - 1;                         // double, add x, (double, double, add)*
+  const uint32_t n_tree = n_weigh + 4, n_all = n_tree + 5;
+  P x = P::identity(), x2 = P::identity(), x3 = P::identity();
   uint32_t k = 0;
+  if (i < cnt) {
+    const uint32_t idx = fam ? rows + i : (i == 0 ? rows + cols - 1 : i);
+    x = xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)idx);
+    k = fam ? i + 1 : (i == 0 ? 1u : i);
+  }
+  P r = x;
   H2_STAMP(0);
 #pragma nounroll
   for (uint32_t pc = 0; pc < n_all; pc++) {
     bool is_double = false, wanted = true;
     P o = P::identity();
-    uint32_t s = 0, it = 0;
-    if (pc < n_weigh) {
-      it = pc / per_item;
-      s = pc - it * per_item;
-      if (s == 0) {                                              // next item: r = x, then 2x
-        const uint32_t i = first + quad + 64 * it;
-        x = P::identity();
-        k = 0;
-        if (i < cnt) {
-          const uint32_t idx = fam ? rows + i : (i == 0 ? rows + cols - 1 : i);
-          x = xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)idx);
-          k = fam ? i + 1 : (i == 0 ? 1u : i);
-        }
-        r = x;
-        is_double = true;
-      } else if (s == 1) {                                       // 3x
-        o = x;
-      } else if (s == per_item - 1) {                            // onto the items before
-        o = acc;
-        wanted = it > 0;
-      } else {
-        const uint32_t t = s - 2, d = ndig - 2 - t / 3;
-        if (t % 3 < 2) is_double = true;
-        else o = xyzz29_pick((k >> (2 * d)) & 3u, x, x2, x3);
-      }
+    if (pc == 0) {
+      is_double = true;                                          // 2x
+    } else if (pc == 1) {
+      o = x;                                                     // 3x
+    } else if (pc < n_weigh) {
+      const uint32_t t = pc - 2, d = ndig - 2 - t / 3;
+      if (t % 3 < 2) is_double = true;
+      else o = xyzz29_pick((k >> (2 * d)) & 3u, x, x2, x3);
     } else if (pc < n_tree) {
       const uint32_t d = 32u >> (pc - n_weigh);
       o = xyzz_shfl_down(r, d);
       wanted = lane < d;
+    } else if (pc == n_tree) {
+      // the last block: every quad holds partial `quad` and now adds partial `quad + 16`
+      if (quad + 16 < nb) o = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_MAX_BLOCKS + quad + 16));
     } else {
-      const uint32_t c = pc - n_tree;                            // the last block: fold 8, fold 4, lb doublings, + columns
-      if (c < 2) {
-        o = xyzz_shfl_down(r, 8u >> c);
-        wanted = (lane & 15u) < (8u >> c);
-      } else if (c < 2 + lb) {
-        if (c == 2) keep = xyzz_shfl_down(r, 16);                // quad 0 receives quad 4's sum (the column family)
-        is_double = true;
-      } else {
-        o = keep;
-      }
+      const uint32_t d = 32u >> (pc - n_tree - 1);
+      o = xyzz_shfl_down(r, d);
+      wanted = lane < d;
     }
     if (is_double) r = xyzz29_double_quad(r);
     else if (wanted) r = xyzz29_add_quad(r, o);
-    if (pc < n_weigh) {
-      if (s == 0) x2 = r;
-      else if (s == 1) {
-        x3 = r;
-        r = xyzz29_pick((k >> (2 * (ndig - 1))) & 3u, x, x2, x3);
-      }
-      if (s == per_item - 1) acc = r;
+    if (pc == 0) x2 = r;
+    else if (pc == 1) {
+      x3 = r;
+      r = xyzz29_pick((k >> (2 * (ndig - 1))) & 3u, x, x2, x3);
     }
     if (pc + 1 == n_tree) {
       // this wave's partial is complete: publish it, and only the block that arrives last goes on
       H2_STAMP(2);
       uint32_t arrived = 0;
       if (threadIdx.x == 0) {
-        xyzz29_store<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + blockIdx.x), r);
+        xyzz29_store<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_MAX_BLOCKS + blockIdx.x), r);
         h2_publish_release();                            // the partial is visible device-wide before the count
         arrived = atomicAdd(done + col, 1u);
       }
       arrived = __shfl(arrived, 0, 64);
       H2_STAMP(3);
-      if (arrived != MSM_FINAL_BLOCKS - 1) return;
+      if (arrived != nb - 1) return;
       h2_consume_acquire();
-      // quads 0-3: row-family partials, quads 4-7: column-family partials
       r = P::identity();
-      if (quad < MSM_FINAL_BLOCKS) r = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_BLOCKS + quad));
+      if (quad < nb) r = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_MAX_BLOCKS + quad));
       H2_STAMP(4);
     }
   }
@@ -1103,7 +1122,18 @@ fixed_base_mul_kernel(U128* __restrict__ out, const U128* __restrict__ scalars, 
 }
 
 // ---- workspace layout -------------------------------------------------------------------------
+// The arena is a sequence of named regions.  msm_check() proves, on the host and before anything is enqueued, that the
+// index ranges of every kernel of the launch sequence lie inside their regions; a guard build of the layout
+// (msm_workspace(..., guard)) puts a red zone behind every region, which tests fill with a pattern before the launch
+// and inspect after it (h2_selftest_msm_guard): an overrun that stays inside the arena corrupts silently otherwise.
+constexpr uint32_t MSM_WS_REGIONS = 32;
+constexpr uint8_t MSM_GUARD_BYTE = 0xA5;
+struct MsmRegion {
+  const char* name;
+  size_t off, bytes;
+};
 struct MsmWorkspace {
+  size_t n, m;          // the shape the layout was made for
   size_t K;             // keys = m * B
   size_t E;             // max entries = m * W * n
   size_t nblk;          // scan blocks
@@ -1113,15 +1143,36 @@ struct MsmWorkspace {
   uint32_t tile;        // scalars per block in the digits / scatter kernels
   uint32_t staged;      // the scatter stages its tile in LDS (msm_scatter_staged_kernel); stage_lds bytes of dynamic LDS
   size_t stage_lds;
+  uint32_t sort2;       // the two-level sort (h2_msm_sort2.hpp) instead of digits / scan / scatter
+  Sort2Geom s2;
   uint32_t lb;          // low bits of a bucket index in the row / column split of the weights (msm_rowcol_kernel)
   uint32_t rc;          // row + column sums per column = 2^(log_b - lb) + 2^lb
   size_t off_counts, off_gcounts, off_offsets, off_tile_base, off_tile_hist, off_blocksums, off_ref, off_key, off_misc, off_bsum,
       off_head, off_tail, off_xsum, off_rc, off_part, off_done, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
+  size_t off_cstart, off_mid_ref, off_mid_lo;   // two-level sort only
+  size_t zero_bytes;    // misc + the counters behind it: cleared by one memset per launch
   uint32_t max_tasks;
+  uint32_t guard;       // bytes of red zone behind every region (0 in the product path)
+  uint32_t n_regions;
+  MsmRegion regions[MSM_WS_REGIONS];
 };
 inline size_t h2_align256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
+
+// which sort a launch of m columns of n scalars uses
+inline bool msm_use_sort2(size_t n, size_t m, const MsmGeom& g) {
+  const int forced = tune_int("H2_TUNE_SORT2", -1);                 // tuning builds only (h2_tune.hpp)
+  const Sort2Geom s = msm_sort2_geom(n, g);
+  const bool fits = g.B >= S2_MAX_F / 8 && s.F <= S2_MAX_F && (size_t)s.Hc * m <= S2_MAX_H;
+  if (forced >= 0) return forced != 0 && fits;
+  // wide windows: a tile of the one-level sort has less than one entry per bucket, its stores leave one by one
+  return fits && g.B > 4096;
+}
+
+inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g, uint32_t guard = 0) {
   MsmWorkspace ws{};
+  ws.n = n;
+  ws.m = m;
+  ws.guard = guard;
   ws.K = m * g.B;
   ws.E = m * g.W * n;
   ws.nblk = (ws.K + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -1129,13 +1180,14 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   // the SIMDs that hold the most waves: pick T so that the launch is a WHOLE number w of waves per SIMD (1024 SIMDs
   // x 64 lanes = 65536 threads per unit of w) and w * T is smallest; fewer, longer chunks also mean fewer pieces for
   // the fix-up.  Big inputs take T = 64 and several rounds, where the rounding no longer matters.
-  uint64_t T = 64;
+  const uint64_t t_max = (uint64_t)tune_int("H2_TUNE_TMAX", 64);
+  uint64_t T = t_max;
   {
     uint64_t best = ~0ull;
     for (uint64_t w = MSM_CHUNK_WAVES; w >= 2; w--) {
       uint64_t t = (ws.E + w * 65536 - 1) / (w * 65536);
       if (t < 8) t = 8;
-      if (t > 64) continue;
+      if (t > t_max) continue;
       const uint64_t cost = w * t * (w == 2 ? 21 : 20);      // two waves per SIMD hide a little less latency
       if (cost < best) { best = cost; T = t; }
     }
@@ -1158,6 +1210,8 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   lq = (uint32_t)tune_int("H2_TUNE_LQ", (int)lq);   // tuning builds only (h2_tune.hpp)
   uint32_t lg = lq + 2;
   ws.log_g = lg;
+  ws.sort2 = msm_use_sort2(n, m, g) ? 1u : 0u;
+  ws.s2 = msm_sort2_geom(n, g);
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
   size_t tile = (n * m + 1023) / 1024;
   // a tile should carry a few entries per bucket, or zeroing / flushing the LDS histogram dominates
@@ -1171,7 +1225,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   // few as fit, two at most (m = 4 at 2^16: 256 blocks of 1024 scalars, 152 KB; m = 5: 512 blocks of 640).
   ws.staged = 0;
   ws.stage_lds = 0;
-  {
+  if (!ws.sort2) {
     const size_t cap = 160 * 1024 - 512;
     auto need = [&](size_t t) { return (size_t)8 * g.B + (size_t)6 * t * g.W + 64; };
     if (g.B <= 65536 && n * m >= 8192 && need(dense) <= cap) {
@@ -1195,31 +1249,150 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g) {
   ws.lb = (g.c - 1) / 2;
   ws.rc = (1u << (g.c - 1 - ws.lb)) + (1u << ws.lb);
   size_t o = 0;
-  ws.off_misc = o; o += 256;                                      // misc[0] = hot task counter; zeroed with counts
-  ws.off_counts = o; o = h2_align256(o + ws.K * 4);                // per-key totals (only the multi-kernel scan reads them)
-  ws.off_gcounts = o; o = h2_align256(o + MSM_XCDS * ws.K * 4);    // per XCD group; zeroed with misc and counts
-  ws.off_offsets = o; o = h2_align256(o + (ws.K + 1) * 4);
-  ws.off_tile_base = o; o = h2_align256(o + ((n + ws.tile - 1) / ws.tile) * ws.K * 4);   // tiles x (m * B) words
-  ws.off_tile_hist = o; o = h2_align256(o + (ws.staged ? ((n + ws.tile - 1) / ws.tile) * ws.K * 4 : 0));
-  ws.off_blocksums = o; o = h2_align256(o + (ws.nblk + 1) * 4);
-  ws.off_ref = o; o = h2_align256(o + ws.E * 4 + 16);             // + slack for the last 16-byte read
-  ws.off_key = o; o = h2_align256(o + (ws.nchunks + 1) * 4);     // chunk_first
-  ws.off_bsum = o; o = h2_align256(o + ws.K * (XYZZ29_WORDS * 4));
-  ws.off_head = o; o = h2_align256(o + ws.nchunks * (XYZZ29_WORDS * 4));
-  ws.off_tail = o; o = h2_align256(o + ws.nchunks * (XYZZ29_WORDS * 4));
-  ws.off_xsum = o; o = h2_align256(o + ws.K * (XYZZ29_WORDS * 4));
-  ws.off_rc = o; o = h2_align256(o + m * ws.rc * (XYZZ29_WORDS * 4));
-  ws.off_part = o; o = h2_align256(o + m * MSM_FINAL_BLOCKS * (XYZZ29_WORDS * 4));
-  ws.off_done = o; o = h2_align256(o + m * 4);
-  ws.off_tree2 = o; o = h2_align256(o + m * (XYZZ29_WORDS * 4));
+  auto region = [&](const char* name, size_t bytes) {
+    const size_t at = o;
+    if (ws.n_regions < MSM_WS_REGIONS) ws.regions[ws.n_regions++] = MsmRegion{name, at, bytes};
+    o = h2_align256(o + bytes) + (guard ? h2_align256(guard) : 0);
+    return at;
+  };
+  const size_t tiles = (n + ws.tile - 1) / ws.tile;
+  if (ws.sort2) {
+    const size_t H = (size_t)ws.s2.Hc * m, t2 = (size_t)ws.s2.tiles * m;
+    // misc[0] = hot task counter, misc + 16: per-column table pointers; then the coarse bins' counters
+    ws.zero_bytes = 256 + H * 4;
+    ws.off_misc = region("zeroed: misc + coarse counters", ws.zero_bytes);
+    ws.off_gcounts = ws.off_misc + 256;
+    ws.off_counts = ws.off_gcounts;
+    ws.off_cstart = region("coarse bin starts", (H + 1) * 4);
+    ws.off_offsets = region("offsets", (ws.K + 1) * 4);
+    ws.off_tile_base = region("tile bases", t2 * ws.s2.Hc * 4);
+    ws.off_tile_hist = region("tile counts", t2 * ws.s2.Hc * 4);
+    ws.off_mid_ref = region("coarse-sorted entries", ws.E * 4);
+    ws.off_mid_lo = region("coarse-sorted low key bits", ws.E);
+    ws.off_blocksums = ws.off_cstart;     // unused
+  } else {
+    // misc (256 B), per-key totals (only the multi-kernel scan reads them), the per-XCD-group counters
+    ws.zero_bytes = 256 + h2_align256(ws.K * 4) + MSM_XCDS * ws.K * 4;
+    ws.off_misc = region("zeroed: misc + counts + group counters", ws.zero_bytes);
+    ws.off_counts = ws.off_misc + 256;
+    ws.off_gcounts = ws.off_counts + h2_align256(ws.K * 4);
+    ws.off_offsets = region("offsets", (ws.K + 1) * 4);
+    ws.off_tile_base = region("tile bases", tiles * ws.K * 4);                       // tiles x (m * B) words
+    ws.off_tile_hist = region("tile counts", ws.staged ? tiles * ws.K * 4 : 0);
+    ws.off_blocksums = region("scan block sums", (ws.nblk + 1) * 4);
+  }
+  ws.off_ref = region("sorted entries", ws.E * 4 + 16);                              // + slack for the last 16-byte read
+  ws.off_key = region("chunk first keys", (ws.nchunks + 1) * 4);
+  ws.off_bsum = region("bucket sums", ws.K * (XYZZ29_WORDS * 4));
+  ws.off_head = region("chunk heads", ws.nchunks * (XYZZ29_WORDS * 4));
+  ws.off_tail = region("chunk tails", ws.nchunks * (XYZZ29_WORDS * 4));
+  ws.off_xsum = region("bucket point sums", ws.K * (XYZZ29_WORDS * 4));
+  ws.off_rc = region("row / column sums", m * ws.rc * (XYZZ29_WORDS * 4));
+  ws.off_part = region("final partials", m * MSM_FINAL_MAX_BLOCKS * (XYZZ29_WORDS * 4));
+  ws.off_done = region("final counters", m * 4);
+  ws.off_tree2 = region("results", m * (XYZZ29_WORDS * 4));
   // hot keys: a key with span > MSM_HOT_SPAN emits ceil(span / SEG) <= span / SEG + 1 <= span / SEG + span / SPAN
   // tasks, and the spans of all keys add up to at most nchunks + K_hot <= nchunks * (1 + 1 / SPAN)
   ws.max_tasks = (uint32_t)(ws.nchunks / MSM_HOT_SEG + 2 * (ws.nchunks / MSM_HOT_SPAN) + 16);
-  ws.off_hot_slot = o; o = h2_align256(o + ws.K * 4);
-  ws.off_hot_tasks = o; o = h2_align256(o + (size_t)ws.max_tasks * 8);
-  ws.off_hot_part = o; o = h2_align256(o + (size_t)ws.max_tasks * (XYZZ29_WORDS * 4));
+  ws.off_hot_slot = region("hot slots", ws.K * 4);
+  ws.off_hot_tasks = region("hot tasks", (size_t)ws.max_tasks * 8);
+  ws.off_hot_part = region("hot partials", (size_t)ws.max_tasks * (XYZZ29_WORDS * 4));
   ws.total = o;
   return ws;
+}
+
+// Host-side proof that the launch sequence stays inside the regions above: every kernel's largest index against the
+// bytes of the array it indexes, the grid sizes against the hardware's limits, the dynamic LDS against the CU's.
+// Returns null, or the first violated condition (msm_launch then enqueues nothing).
+#define MSM_REQUIRE(cond) \
+  do {                    \
+    if (!(cond)) return #cond; \
+  } while (0)
+inline const char* msm_check(const MsmWorkspace& ws, const MsmGeom& g, size_t n, size_t m, size_t col_stride,
+                             uint32_t n_bases, size_t arena_bytes) {
+  auto bytes_at = [&](size_t off) -> size_t {
+    for (uint32_t r = 0; r < ws.n_regions; r++)
+      if (off >= ws.regions[r].off && off < ws.regions[r].off + ws.regions[r].bytes)    // (an empty region holds nothing)
+        return ws.regions[r].off + ws.regions[r].bytes - off;
+    return 0;
+  };
+  MSM_REQUIRE(ws.n == n && ws.m == m);                                   // the layout was made for this launch
+  MSM_REQUIRE(n >= 1 && m >= 1 && n <= n_bases);
+  MSM_REQUIRE(m == 1 || col_stride >= n);
+  MSM_REQUIRE(ws.n_regions < MSM_WS_REGIONS);
+  MSM_REQUIRE(ws.total <= arena_bytes);
+  for (uint32_t r = 0; r + 1 < ws.n_regions; r++)
+    MSM_REQUIRE(ws.regions[r].off + ws.regions[r].bytes + ws.guard <= ws.regions[r + 1].off);
+  MSM_REQUIRE(ws.regions[ws.n_regions - 1].off + ws.regions[ws.n_regions - 1].bytes + ws.guard <= ws.total);
+  MSM_REQUIRE(g.W >= 1 && g.W <= MSM_MAX_WINDOWS && g.B == (1u << (g.c - 1)) && g.c <= MSM_MAX_C);
+  MSM_REQUIRE((uint64_t)g.W * n_bases < (1ull << 31));                  // an entry is w * n_bases + i below the sign bit
+  MSM_REQUIRE(ws.K == m * (size_t)g.B && ws.E == m * (size_t)g.W * n);
+  MSM_REQUIRE(ws.E < (1ull << 31) && ws.K < (1ull << 31));
+  MSM_REQUIRE(bytes_at(ws.off_misc) >= ws.zero_bytes && ws.zero_bytes >= 256);
+  MSM_REQUIRE(bytes_at(ws.off_offsets) >= (ws.K + 1) * 4);
+  if (ws.sort2) {
+    const Sort2Geom& s = ws.s2;
+    const size_t H = (size_t)s.Hc * m;
+    MSM_REQUIRE(s.F * s.Hc == g.B && s.F == (1u << s.lo_bits) && s.F <= S2_MAX_F && s.Hc <= S2_MAX_HC && H <= S2_MAX_H);
+    MSM_REQUIRE(s.tile >= 1 && s.tile <= S2_THREADS && (size_t)s.tile * g.W <= S2_STAGE);
+    MSM_REQUIRE((size_t)s.tiles * s.tile >= n && (size_t)(s.tiles - 1) * s.tile < n);
+    MSM_REQUIRE(s.tiles <= 0x7FFFFFFFu && m <= 65535);                  // grid (tiles, m)
+    MSM_REQUIRE(ws.off_gcounts == ws.off_misc + 256 && ws.zero_bytes >= 256 + H * 4);
+    MSM_REQUIRE(bytes_at(ws.off_cstart) >= (H + 1) * 4);
+    MSM_REQUIRE(bytes_at(ws.off_tile_base) >= (size_t)s.tiles * m * s.Hc * 4);
+    MSM_REQUIRE(bytes_at(ws.off_tile_hist) >= (size_t)s.tiles * m * s.Hc * 4);
+    MSM_REQUIRE(bytes_at(ws.off_mid_ref) >= ws.E * 4 && bytes_at(ws.off_mid_lo) >= ws.E);
+    MSM_REQUIRE((size_t)s.Hc * 4 <= 64 * 1024);
+    MSM_REQUIRE(msm_sort2_lds_scatter(s, g) <= 160 * 1024 - 512 && msm_sort2_lds_fine() + 4 * S2_MAX_F * 4 <= 160 * 1024 - 512);
+  } else {
+    const size_t tiles = (n + ws.tile - 1) / ws.tile;
+    MSM_REQUIRE(ws.tile >= 1 && tiles * m < (1ull << 31) - MSM_XCDS);
+    MSM_REQUIRE(msm_tile_grid((uint32_t)tiles, (uint32_t)m) >= tiles * m);
+    MSM_REQUIRE((size_t)g.B * 4 <= 128 * 1024);                          // the LDS histogram of the digits / scatter kernels
+    MSM_REQUIRE(ws.off_counts == ws.off_misc + 256 && ws.off_gcounts >= ws.off_counts + ws.K * 4);
+    MSM_REQUIRE(ws.off_gcounts + MSM_XCDS * ws.K * 4 <= ws.off_misc + ws.zero_bytes);
+    MSM_REQUIRE(bytes_at(ws.off_tile_base) >= tiles * ws.K * 4);
+    if (ws.staged) {
+      MSM_REQUIRE(bytes_at(ws.off_tile_hist) >= tiles * ws.K * 4);
+      MSM_REQUIRE(g.B <= 65536);                                         // staged buckets are 16-bit
+      MSM_REQUIRE(ws.stage_lds >= (size_t)8 * g.B + (size_t)6 * ws.tile * g.W && ws.stage_lds <= 160 * 1024 - 512);
+    }
+    if (ws.K > SCAN_LDS_MAX) {
+      MSM_REQUIRE(ws.nblk * SCAN_BLOCK >= ws.K && ws.nblk < (1ull << 31));
+      MSM_REQUIRE(bytes_at(ws.off_blocksums) >= (ws.nblk + 1) * 4);
+    }
+  }
+  MSM_REQUIRE(bytes_at(ws.off_ref) >= ((ws.E + 3) & ~(size_t)3) * 4);  // 16-byte reads of the last entries
+  // chunks the device may cut (msm_effective_t): t = max(8, ceil(E' / (3 * 65536))) capped at T, for any E' <= E
+  MSM_REQUIRE(ws.T >= 8 && ws.nchunks >= (ws.E + ws.T - 1) / ws.T);
+  MSM_REQUIRE(ws.nchunks >= std::min<size_t>((ws.E + 7) / 8, (size_t)MSM_CHUNK_WAVES * 65536 + 1));
+  MSM_REQUIRE((ws.nchunks + 255) / 256 < (1ull << 31));
+  MSM_REQUIRE(bytes_at(ws.off_key) >= ws.nchunks * 4);
+  MSM_REQUIRE(bytes_at(ws.off_head) >= ws.nchunks * (XYZZ29_WORDS * 4) && bytes_at(ws.off_tail) >= ws.nchunks * (XYZZ29_WORDS * 4));
+  MSM_REQUIRE(bytes_at(ws.off_bsum) >= ws.K * (XYZZ29_WORDS * 4) && bytes_at(ws.off_xsum) >= ws.K * (XYZZ29_WORDS * 4));
+  MSM_REQUIRE(ws.log_g >= 2 && ws.log_g <= 6 && ((ws.K << ws.log_g) + 255) / 256 < (1ull << 31));
+  MSM_REQUIRE(ws.lb < g.c && ws.rc == (1u << (g.c - 1 - ws.lb)) + (1u << ws.lb));
+  MSM_REQUIRE(bytes_at(ws.off_rc) >= m * ws.rc * (XYZZ29_WORDS * 4));
+  MSM_REQUIRE(msm_final_blocks(g.c - 1, ws.lb) <= MSM_FINAL_MAX_BLOCKS);
+  MSM_REQUIRE(bytes_at(ws.off_part) >= m * MSM_FINAL_MAX_BLOCKS * (XYZZ29_WORDS * 4));
+  MSM_REQUIRE(bytes_at(ws.off_done) >= m * 4 && bytes_at(ws.off_tree2) >= m * (XYZZ29_WORDS * 4));
+  MSM_REQUIRE(bytes_at(ws.off_hot_slot) >= ws.K * 4);
+  MSM_REQUIRE(bytes_at(ws.off_hot_tasks) >= (size_t)ws.max_tasks * 8);
+  MSM_REQUIRE(bytes_at(ws.off_hot_part) >= (size_t)ws.max_tasks * (XYZZ29_WORDS * 4));
+  MSM_REQUIRE(m <= 65535);                                               // grid.y of the row / column and final kernels
+  return nullptr;
+}
+#undef MSM_REQUIRE
+
+// guard builds of the layout: count the red-zone bytes that no longer hold the pattern (one block per region)
+static __global__ void __launch_bounds__(256)
+msm_guard_check_kernel(const uint8_t* __restrict__ arena, MsmWorkspace ws, uint32_t* __restrict__ bad /* per region */) {
+  const uint32_t r = blockIdx.x;
+  const size_t from = ws.regions[r].off + ws.regions[r].bytes;
+  const size_t to = r + 1 < ws.n_regions ? ws.regions[r + 1].off : ws.total;
+  uint32_t c = 0;
+  for (size_t i = from + threadIdx.x; i < to; i += blockDim.x) c += arena[i] != MSM_GUARD_BYTE;
+  if (c) atomicAdd(&bad[r], c);
 }
 
 // once per device (h2_init): the sort kernels and the one-block scan use more than the default 64 KiB of dynamic LDS
@@ -1230,6 +1403,8 @@ inline hipError_t msm_kernel_setup() {
   if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)msm_scatter_staged_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)msm2_scatter_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)msm2_fine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_sort2_lds_fine())) != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)scan_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCAN_LDS_MAX * 4));
 }
 
@@ -1261,40 +1436,55 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   uint32_t* hot_tasks = (uint32_t*)(ws_base + ws.off_hot_tasks);
   uint32_t* hot_part = (uint32_t*)(ws_base + ws.off_hot_part);
   hipError_t e;
-  // one memset: misc (256 B) sits directly before counts.  Nothing else needs clearing: every slot of bucket_sum /
+  if (per_column && m > MSM_MAX_MULTI) return hipErrorInvalidValue;
+  // one memset: misc (256 B) and the sort's counters behind it.  Nothing else needs clearing: every slot of bucket_sum /
   // head / tail that a later kernel reads has been written by the accumulate kernel (the fix-up decides from
   // `offsets` which slots exist).
-  if ((e = hipMemsetAsync(misc, 0, ws.off_gcounts + MSM_XCDS * ws.K * 4 - ws.off_misc, stream)) != hipSuccess) return e;
-  const size_t lds = (size_t)g.B * 4;     // dynamic LDS limits were raised once per device by msm_kernel_setup
-  const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
-  const uint32_t sort_grid = msm_tile_grid(tiles, (uint32_t)m);
-  uint32_t* tile_hist = ws.staged ? (uint32_t*)(ws_base + ws.off_tile_hist) : nullptr;
-  hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, gcounts,
-                     tile_base, tile_hist, (uint32_t)n, col_stride, ws.tile, tiles, (uint32_t)m, g);
-  if (ws.K <= SCAN_LDS_MAX) {
-    uint32_t per = (uint32_t)((ws.K + 1023) / 1024);
-    per |= 1u;                                 // odd stride: the per-thread LDS walks do not collide on banks
-    hipLaunchKernelGGL(scan_lds_kernel, dim3(1), dim3(1024), ws.K * 4, stream, gcounts, offsets, (uint32_t)ws.K, per);
+  if ((e = hipMemsetAsync(misc, 0, ws.zero_bytes, stream)) != hipSuccess) return e;
+  uint32_t* tile_hist = (ws.staged || ws.sort2) ? (uint32_t*)(ws_base + ws.off_tile_hist) : nullptr;
+  if (ws.sort2) {
+    const Sort2Geom& s2 = ws.s2;
+    const uint32_t H = s2.Hc * (uint32_t)m;
+    uint32_t* cstart = (uint32_t*)(ws_base + ws.off_cstart);
+    uint32_t* mid_ref = (uint32_t*)(ws_base + ws.off_mid_ref);
+    uint8_t* mid_lo = (uint8_t*)(ws_base + ws.off_mid_lo);
+    hipLaunchKernelGGL(msm2_count_kernel<CV>, dim3(s2.tiles, (unsigned)m), dim3(S2_THREADS), (size_t)s2.Hc * 4, stream, d_scalars,
+                       gcounts, tile_base, tile_hist, (uint32_t)n, col_stride, s2, g);
+    hipLaunchKernelGGL(msm2_coarse_scan_kernel, dim3(1), dim3(1024), 0, stream, gcounts, cstart, H, offsets + ws.K);
+    hipLaunchKernelGGL(msm2_scatter_kernel<CV>, dim3(s2.tiles, (unsigned)m), dim3(S2_THREADS), msm_sort2_lds_scatter(s2, g), stream,
+                       d_scalars, cstart, tile_base, tile_hist, mid_ref, mid_lo, (uint32_t)n, col_stride, n_bases, s2, g);
+    hipLaunchKernelGGL(msm2_fine_kernel, dim3(H), dim3(S2_THREADS), msm_sort2_lds_fine(), stream, cstart, mid_ref, mid_lo, sref,
+                       offsets, s2.F, s2.lo_bits);
   } else {
-  hipLaunchKernelGGL(msm_group_fold_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, gcounts, counts, ws.K);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
-  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
-                     ws.K);
+    const size_t lds = (size_t)g.B * 4;     // dynamic LDS limits were raised once per device by msm_kernel_setup
+    const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);
+    const uint32_t sort_grid = msm_tile_grid(tiles, (uint32_t)m);
+    hipLaunchKernelGGL(msm_digits_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, gcounts,
+                       tile_base, tile_hist, (uint32_t)n, col_stride, ws.tile, tiles, (uint32_t)m, g);
+    if (ws.K <= SCAN_LDS_MAX) {
+      uint32_t per = (uint32_t)((ws.K + 1023) / 1024);
+      per |= 1u;                                 // odd stride: the per-thread LDS walks do not collide on banks
+      hipLaunchKernelGGL(scan_lds_kernel, dim3(1), dim3(1024), ws.K * 4, stream, gcounts, offsets, (uint32_t)ws.K, per);
+    } else {
+      hipLaunchKernelGGL(msm_group_fold_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, gcounts, counts, ws.K);
+      hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, ws.K);
+      hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, stream, blocksums, (uint32_t)ws.nblk, misc + 1);
+      hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
+                         ws.K);
+    }
+    if (ws.staged)
+      hipLaunchKernelGGL(msm_scatter_staged_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), ws.stage_lds, stream, d_scalars,
+                         offsets, gcounts, tile_base, tile_hist, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles,
+                         (uint32_t)m, g, (uint32_t)(ws.tile * g.W));
+    else
+      hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
+                         gcounts, tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles, (uint32_t)m, g);
   }
-  if (ws.staged)
-    hipLaunchKernelGGL(msm_scatter_staged_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), ws.stage_lds, stream, d_scalars,
-                       offsets, gcounts, tile_base, tile_hist, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles,
-                       (uint32_t)m, g, (uint32_t)(ws.tile * g.W));
-  else
-    hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
-                       gcounts, tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles, (uint32_t)m, g);
   hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
                      chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
   const U128** d_tables = nullptr;
   uint32_t log_b = 0;
   if (per_column) {
-    if (m > MSM_MAX_MULTI) return hipErrorInvalidValue;
     MsmTableList L{};
     for (size_t j = 0; j < m; j++) L.t[j] = per_column[j];
     d_tables = (const U128**)(misc + 16);                          // 128 bytes of the 256-byte misc block
@@ -1313,9 +1503,10 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
                      ws.K, ws.T, ws.log_g, bsum, head, tail, hot_slot, hot_part, xsum);
   uint32_t* part = (uint32_t*)(ws_base + ws.off_part);
   uint32_t* done = (uint32_t*)(ws_base + ws.off_done);
-  hipLaunchKernelGGL(msm_rowcol_kernel<CV>, dim3(ws.rc, (unsigned)m), dim3(64), 0, stream, xsum, rc, done, g.c - 1, ws.lb);
-  hipLaunchKernelGGL(msm_final_kernel<CV>, dim3(MSM_FINAL_BLOCKS, (unsigned)m), dim3(64), 0, stream, rc, part, done, tree2,
-                     d_out_jac, g.c - 1, ws.lb);
+  hipLaunchKernelGGL(msm_rowcol_kernel<CV>, dim3(ws.rc, (unsigned)m), dim3(64 * msm_rowcol_waves(g.c - 1, ws.lb, m)), 0, stream,
+                     xsum, rc, done, g.c - 1, ws.lb);
+  hipLaunchKernelGGL(msm_final_kernel<CV>, dim3(msm_final_blocks(g.c - 1, ws.lb), (unsigned)m), dim3(64), 0, stream, rc, part,
+                     done, tree2, d_out_jac, g.c - 1, ws.lb);
   return hipGetLastError();
 }
 

@@ -38,6 +38,22 @@ int h2_selftest_digits(int curve, const uint64_t scalar[4], size_t n_for_geometr
 /* test hook: cap the entries one sort launch may hold, so that the grouped-columns path of wide batches is reached
  * at small sizes; 0 restores the default (2^31 - 1). */
 int h2_selftest_set_msm_max_entries(uint64_t limit);
+/* MSM workspace checks.
+ * h2_selftest_msm_check: host only, no GPU -- lays out the scratch arena of a launch of m columns of n scalars
+ *   (col_stride elements apart) against n_bases registered bases and runs the bounds proof msm_device_run runs before
+ *   every launch (each kernel's largest index against the region it indexes).  out[0..7] = window bits, windows,
+ *   buckets, scalars per sort tile, staged scatter?, two-level sort?, entries per accumulate thread, regions.
+ * h2_selftest_msm_tiles: host only -- the one-level sort's block -> (column, tile) mapping is a bijection onto the
+ *   live pairs and every surplus block of the rounded-up grid is dead.
+ * h2_selftest_msm_guard(1): from now on every MSM launch lays its arena out with a 256-byte red zone behind every
+ *   region, fills the arena with a pattern first and counts the red-zone bytes that changed afterwards (synchronous;
+ *   tests only; guard(2) also writes one byte behind the second region itself, to test the checker).
+ *   h2_selftest_msm_guard_report: out[0] = launches checked, out[1] = regions overrun since guard(1);
+ *   `first` = a description of the first one. */
+int h2_selftest_msm_check(int curve, size_t n_bases, size_t n, size_t m, size_t col_stride, int guard, uint64_t out[8]);
+int h2_selftest_msm_tiles(uint32_t tiles, uint32_t m);
+int h2_selftest_msm_guard(int on);
+int h2_selftest_msm_guard_report(uint64_t out[2], char* first, size_t cap);
 /* the integer ceiling the MSM kernels are priced against: dependent products of the MSM's working field form
  * (9 x 29-bit limbs) over `curve`'s base field, every CU busy with `waves_per_simd` waves per SIMD; measured
  * chip-wide modmul/s (best of three launches).  bench.py reports it as `modmul_ceiling`. */

@@ -1,0 +1,128 @@
+"""GPU: MSM launches of awkward shapes with a red zone behind every region of the scratch arena.
+
+The shapes are those the round-2 review asked for after the recorded memory-access fault:
+tiles * m not a multiple of 8 (surplus blocks of the XCD-grouped grid), m = 3 / 5 / 7 at 2^16, ragged lengths, prefixes
+of the registered bases, the staged and the direct scatter, the two-level sort, first call with the profiling events
+on.  `h2_selftest_msm_guard(1)` lays the arena out with 256 guard bytes behind every region, fills it with a pattern
+before each launch sequence and counts the guard bytes that changed; results are compared with the CPU oracle.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+SEED = 0x48324D5300000000
+CID = O.CURVE_IDS
+
+
+def scalars(curve, n, seed):
+    return O.synth_scalars(O.CURVE_SCALAR_FIELD[CID[curve]], SEED | seed, n).reshape(n, 4)
+
+
+def bases_of(curve, n, seed=0xB5):
+    return O.synth_bases(CID[curve], SEED | seed, n, threads=8).reshape(n, 8)
+
+
+def guard_report(lib):
+    out = (ctypes.c_uint64 * 2)()
+    first = ctypes.create_string_buffer(256)
+    assert lib.h2_selftest_msm_guard_report(out, first, 256) == 0
+    return int(out[0]), int(out[1]), first.value.decode()
+
+
+@pytest.fixture()
+def guarded(h2):
+    lib = h2.load()
+    lib.h2_selftest_msm_guard(1)
+    yield lib
+    lib.h2_selftest_msm_guard(0)
+
+
+# (curve, registered bases, column length, columns, columns checked against the oracle)
+SHAPES = [
+    ("bn254", 1 << 16, 1 << 16, 3, (0, 2)),            # staged scatter; tiles * m odd multiples
+    ("pallas", 1 << 16, 1 << 16, 5, (4,)),
+    ("bn254", 1 << 16, 1 << 16, 7, (6,)),
+    ("pallas", 1 << 16, (1 << 16) - 5, 3, (1,)),       # ragged: a prefix of the bases, last tile short
+    ("bn254", 1 << 16, 40001, 1, (0,)),
+    ("bn254", 3000, 3000, 3, (0, 1, 2)),                # direct scatter (too few scalars for the staged one)
+    ("pallas", 3000, 2999, 5, (3,)),
+    ("bn254", 1 << 12, 1 << 12, 5, (0, 4)),
+    ("vesta", 1 << 13, 1 << 13, 9, (8,)),
+    ("bn254", 1 << 18, 1 << 18, 1, (0,)),               # two-level sort (8192 buckets)
+    ("pallas", 1 << 18, (1 << 18) - 77, 3, (2,)),
+    ("bn254", 300001, 299999, 2, (1,)),
+]
+
+
+@pytest.mark.parametrize("curve,n_bases,n,m,verify", SHAPES)
+def test_awkward_shapes_stay_inside_their_regions(h2, guarded, curve, n_bases, n, m, verify):
+    lib = guarded
+    lib.h2_profile_enable(1)                            # the roofline events ride along, as in bench.py's timed region
+    b = bases_of(curve, n_bases)
+    bases = h2.Bases(curve, b)
+    try:
+        cols = [scalars(curve, n, 40 + j) for j in range(m)]
+        if m > 1:
+            cols[1][n // 2:] = 0                        # a half-empty column: fewer entries than the worst case
+        got = bases.msm_batch(cols)
+        launches, violations, first = guard_report(lib)
+        assert launches >= 1
+        assert violations == 0, first
+        for j in verify:
+            want = O.to_affine(CID[curve], O.best_multiexp(CID[curve], cols[j], b[:n], threads=8))
+            assert np.array_equal(got[j], want), j
+    finally:
+        lib.h2_profile_enable(0)
+        bases.release()
+
+
+def test_two_level_sort_on_skewed_columns(h2, guarded):
+    """coarse bins far from uniform: a constant column (every entry of a window in ONE bucket: bins of 2^18 entries, many
+    slabs per level-2 block), a 0/1 selector, a sparse column, and a dense one, 2^18 rows each"""
+    import pyref as R
+    lib = guarded
+    curve, n = "bn254", 1 << 18
+    f = R.CURVES[curve].scalar
+    b = bases_of(curve, n)
+    bases = h2.Bases(curve, b)
+    try:
+        const = np.tile(np.array(f.limbs(0x1234567 << 40), dtype=np.uint64), (n, 1))
+        sel = np.zeros((n, 4), dtype=np.uint64)
+        sel[::3] = np.array(f.limbs(1), dtype=np.uint64)
+        sparse = np.zeros((n, 4), dtype=np.uint64)
+        sparse[:64] = scalars(curve, 64, 91)
+        sparse[-6:] = scalars(curve, 6, 92)
+        dense = scalars(curve, n, 93)
+        cols = [const, sel, sparse, dense]
+        got = bases.msm_batch(cols)
+        launches, violations, first = guard_report(lib)
+        assert launches >= 1 and violations == 0, first
+        for j, col in enumerate(cols):
+            want = O.to_affine(CID[curve], O.best_multiexp(CID[curve], col, b, threads=8))
+            assert np.array_equal(got[j], want), j
+        one = bases.msm(const)                          # alone: another chunk size, another bin population
+        assert np.array_equal(O.to_affine(CID[curve], one), got[0])
+        assert guard_report(lib)[1] == 0
+    finally:
+        bases.release()
+
+
+def test_guard_mode_does_catch_an_overrun(h2, guarded):
+    """guard(2) makes the library itself write one byte behind the second region: the checker must report it"""
+    lib = guarded
+    curve, n = "bn254", 1 << 10
+    b = bases_of(curve, n)
+    bases = h2.Bases(curve, b)
+    try:
+        bases.msm(scalars(curve, n, 5))
+        assert guard_report(lib) == (1, 0, "")
+        lib.h2_selftest_msm_guard(2)
+        bases.msm(scalars(curve, n, 5))
+        launches, violations, first = guard_report(lib)
+        assert (launches, violations) == (1, 1) and "1 byte(s) behind the region" in first, first
+    finally:
+        bases.release()

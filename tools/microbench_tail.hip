@@ -67,7 +67,8 @@ static void tail_stages() {
   unsigned long long* stamps;
   hipMalloc(&xsum, (size_t)m * B * XYZZ29_WORDS * 4);
   hipMalloc(&rc, (size_t)m * rcn * XYZZ29_WORDS * 4);
-  hipMalloc(&part, (size_t)m * MSM_FINAL_BLOCKS * XYZZ29_WORDS * 4);
+  hipMalloc(&part, (size_t)m * MSM_FINAL_MAX_BLOCKS * XYZZ29_WORDS * 4);
+  const uint32_t nb = msm_final_blocks(log_b, lb);
   hipMalloc(&done, m * 4);
   hipMalloc(&out, m * XYZZ29_WORDS * 4);
   hipMalloc(&jac, m * 96);
@@ -75,18 +76,18 @@ static void tail_stages() {
   hipMemset(stamps, 0, 16 * 8 * 1024);
   hipMemcpyToSymbol(HIP_SYMBOL(h2_stamps), &stamps, sizeof(stamps));
   hipLaunchKernelGGL(k_fill, dim3((m * B + 255) / 256), dim3(256), 0, 0, xsum, m * B);
-  std::vector<unsigned long long> h(16 * MSM_FINAL_BLOCKS * m);
+  std::vector<unsigned long long> h(16 * nb * m);
   for (int rep = 0; rep < 3; rep++) {
-    hipLaunchKernelGGL(msm_rowcol_kernel<CV>, dim3(rcn, m), dim3(64), 0, 0, xsum, rc, done, log_b, lb);
+    hipLaunchKernelGGL(msm_rowcol_kernel<CV>, dim3(rcn, m), dim3(64 * msm_rowcol_waves(log_b, lb, m)), 0, 0, xsum, rc, done, log_b, lb);
     hipDeviceSynchronize();
     hipMemset(stamps, 0, 16 * 8 * 1024);
-    hipLaunchKernelGGL(msm_final_kernel<CV>, dim3(MSM_FINAL_BLOCKS, m), dim3(64), 0, 0, rc, part, done, out, jac, log_b, lb);
+    hipLaunchKernelGGL(msm_final_kernel<CV>, dim3(nb, m), dim3(64), 0, 0, rc, part, done, out, jac, log_b, lb);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull;
-    for (size_t b = 0; b < MSM_FINAL_BLOCKS * m; b++) if (h[b * 16] && h[b * 16] < t0) t0 = h[b * 16];
-    printf("  msm_final_kernel stages, run %d (us since the first wave started; block = family*4 + part, column 0):\n", rep);
-    for (uint32_t b = 0; b < MSM_FINAL_BLOCKS; b++) {
+    for (size_t b = 0; b < nb * m; b++) if (h[b * 16] && h[b * 16] < t0) t0 = h[b * 16];
+    printf("  msm_final_kernel stages, run %d (us since the first wave started; row-family blocks first, column 0):\n", rep);
+    for (uint32_t b = 0; b < nb; b++) {
       printf("    block %u:", b);
       for (int i = 0; i < 9; i++) {
         if (h[b * 16 + i]) printf(" %7.2f", (double)(h[b * 16 + i] - t0) / 100.0);
@@ -95,7 +96,7 @@ static void tail_stages() {
       printf("\n");
     }
   }
-  printf("  stamps: 0 start, 2 weights and wave tree done, 3 counted, 4 partials loaded, 7 joined, doubled and added, 8 stored\n");
+  printf("  stamps: 0 start, 2 weights and wave tree done, 3 counted, 4 partials loaded, 7 partials added, 8 stored\n");
 }
 
 template <class F>
