@@ -202,7 +202,7 @@ int msm_common_checks(int curve, uint64_t handle, size_t first, size_t n, size_t
 static uint64_t g_msm_max_entries = (1ull << 31) - 1;   // lowered only by h2_selftest_set_msm_max_entries (tests)
 // guard mode (tests only, h2_selftest_msm_guard): the workspace is laid out with a red zone behind every region, filled
 // with a pattern before each launch sequence and inspected after it
-static bool g_msm_guard = false, g_msm_guard_poke = false;
+static bool g_msm_guard = false, g_msm_guard_poke = false, g_sort2_pack = true;
 static uint64_t g_guard_launches = 0, g_guard_violations = 0;
 static std::string g_guard_first;
 static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
@@ -232,7 +232,7 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
   const char* table = (const char*)be.table[ctx_index(&c)] + first_base * 64;
   for (size_t j0 = 0; j0 < m; j0 += group) {
     const size_t mm = m - j0 < group ? m - j0 : group;
-    MsmWorkspace ws = msm_workspace(n, mm, be.geom, g_msm_guard ? 256u : 0u);
+    MsmWorkspace ws = msm_workspace(n, mm, be.geom, g_msm_guard ? 256u : 0u, be.n - first_base, g_sort2_pack);
     if (ws.E >= (1ull << 31) || ws.K >= (1ull << 31)) return H2_EINVAL;
     int rc = arena_acquire(c.msm_ws, ws.total, stream);
     if (rc != H2_OK) return rc;
@@ -985,6 +985,7 @@ extern "C" int h2_selftest_msm_guard(int on) {
   std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   h2::g_msm_guard = on != 0;
   h2::g_msm_guard_poke = on == 2;
+  h2::g_sort2_pack = on != 3;            // guard(3): the two-level sort keeps the low key bits in the side array
   h2::g_guard_launches = h2::g_guard_violations = 0;
   h2::g_guard_first.clear();
   return H2_OK;
@@ -1007,7 +1008,7 @@ extern "C" int h2_selftest_msm_check(int curve, size_t n_bases, size_t n, size_t
   const CurveOps* ops = ops_of(curve);
   if (!ops || n == 0 || m == 0 || n > n_bases) return H2_EINVAL;
   const MsmGeom g = msm_geometry(n_bases, ops->scalar_bits);
-  const MsmWorkspace ws = msm_workspace(n, m, g, guard ? 256u : 0u);
+  const MsmWorkspace ws = msm_workspace(n, m, g, guard ? 256u : 0u, n_bases);
   if (out) {
     out[0] = g.c; out[1] = g.W; out[2] = g.B; out[3] = ws.sort2 ? ws.s2.tile : ws.tile;
     out[4] = ws.staged; out[5] = ws.sort2; out[6] = ws.T; out[7] = ws.n_regions;

@@ -103,7 +103,7 @@ H2_HD Xyzz29<CV> xyzz29_double_affine(const Affine29<CV>& a) {
   const F xx = fe29_sqr(a.x);
   const F m = fe29_norm(fe29_add(fe29_add(xx, xx), xx)); // < 4.5
   const F x3 = fe29_norm(fe29_sub(fe29_sub(fe29_sqr(m), s), s));
-  const F y3 = fe29_norm(fe29_sub(fe29_mul(m, fe29_sub(s, x3)), fe29_mul(w, a.y)));
+  const F y3 = fe29_mul_sub(m, fe29_sub(s, x3), w, a.y);                                 // one reduction for both products
   return Xyzz29<CV>{x3, y3, v, w};
 }
 
@@ -119,7 +119,7 @@ H2_HD Xyzz29<CV> xyzz29_double(const Xyzz29<CV>& p) {
   const F xx = fe29_sqr(p.x);                            // 25
   const F m = fe29_norm(fe29_add(fe29_add(xx, xx), xx)); // < 4.5
   const F x3 = fe29_norm(fe29_sub(fe29_sub(fe29_sqr(m), s), s));                        // (-3.5, 2.5)
-  const F y3 = fe29_norm(fe29_sub(fe29_mul(m, fe29_sub(s, x3)), fe29_mul(w, p.y)));     // 4.5 * 5, 1.5 * 2
+  const F y3 = fe29_mul_sub(m, fe29_sub(s, x3), w, p.y);                                // 4.5 * 5 + 1.5 * 2, one reduction
   return Xyzz29<CV>{x3, y3, fe29_mul(v, p.zz), fe29_mul(w, p.zzz)};
 }
 
@@ -141,7 +141,7 @@ H2_HD Xyzz29<CV> xyzz29_add_affine(const Xyzz29<CV>& acc, const Affine29<CV>& q)
   const F ppp = fe29_mul(p, pp);                         // 6.5 * 1.5
   const F qq = fe29_mul(acc.x, pp);                      // 5 * 1.5
   const F x3 = fe29_norm(fe29_sub(fe29_sub(fe29_sub(fe29_sqr(r), ppp), qq), qq));       // (-5, 3)
-  const F y3 = fe29_norm(fe29_sub(fe29_mul(r, fe29_sub(qq, x3)), fe29_mul(acc.y, ppp))); // 3.5 * 6.5, 2 * 1.5
+  const F y3 = fe29_mul_sub(r, fe29_sub(qq, x3), acc.y, ppp);                            // 3.5 * 6.5 + 2 * 1.5, one reduction
   return Xyzz29<CV>{x3, y3, fe29_mul(acc.zz, pp), fe29_mul(acc.zzz, ppp)};
 }
 
@@ -165,7 +165,7 @@ H2_HD Xyzz29<CV> xyzz29_add(const Xyzz29<CV>& a, const Xyzz29<CV>& b) {
   const F ppp = fe29_mul(p, pp);
   const F qq = fe29_mul(u1, pp);
   const F x3 = fe29_norm(fe29_sub(fe29_sub(fe29_sub(fe29_sqr(r), ppp), qq), qq));
-  const F y3 = fe29_norm(fe29_sub(fe29_mul(r, fe29_sub(qq, x3)), fe29_mul(s1, ppp)));
+  const F y3 = fe29_mul_sub(r, fe29_sub(qq, x3), s1, ppp);
   return Xyzz29<CV>{x3, y3, fe29_mul(fe29_mul(a.zz, b.zz), pp), fe29_mul(fe29_mul(a.zzz, b.zzz), ppp)};
 }
 

@@ -340,7 +340,11 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
   s = fe_from_mont(s);
   out[0] = g.c; out[1] = g.W; out[2] = g.B; out[3] = g.nbits;
   uint32_t carry = 0;
-  for (uint32_t w = 0; w < g.W; w++) out[4 + w] = msm_digit_step(s.v, g, w, carry);
+  MsmDigits dg(s.v);        // the kernels' form (windows taken in order from a shifted scalar) must agree with the indexed one
+  for (uint32_t w = 0; w < g.W; w++) {
+    out[4 + w] = msm_digit_step(s.v, g, w, carry);
+    if (dg.next(g, w) != out[4 + w]) return -3;
+  }
   return carry ? -2 : 0;  // a carry out of the top window would lose value
 }
 

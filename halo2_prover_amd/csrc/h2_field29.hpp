@@ -132,6 +132,14 @@ H2_HD void mac_p(int64_t& acc, int32_t m) {
     acc += (int64_t)m * (int32_t)pj;
   }
 }
+// m with (acc + m p) = 0 mod 2^29: m = acc * (-p^-1) mod 2^29.  For the Pasta primes p = 1 mod 2^29, so that is -acc:
+// a subtraction instead of a quarter-rate v_mul_lo_u32, nine times per product
+template <class FP>
+H2_HD int32_t mont_m(uint32_t acc_lo) {
+  constexpr uint32_t ninv = FP::INV & L29_MASK;
+  if constexpr (ninv == L29_MASK) return (int32_t)((0u - acc_lo) & L29_MASK);
+  else return (int32_t)((acc_lo * ninv) & L29_MASK);
+}
 template <class FP, int K, int I, int IEND>
 H2_HD void col_ab(int64_t& acc, const int32_t* a, const int32_t* b) {
   if constexpr (I <= IEND) {
@@ -153,7 +161,7 @@ H2_HD void columns(int64_t& acc, const int32_t* a, const int32_t* b, int32_t* m,
     col_ab<FP, K, (K < 9 ? 0 : K - 8), (K < 9 ? K : 8)>(acc, a, b);
     if constexpr (K < 9) {
       if constexpr (K > 0) col_mp<FP, K, 0, K - 1>(acc, m);
-      m[K] = (int32_t)(((uint32_t)acc * (FP::INV & L29_MASK)) & L29_MASK);   // -p^-1 mod 2^29
+      m[K] = mont_m<FP>((uint32_t)acc);
       mac_p<FP, 0>(acc, m[K]);
     } else {
       col_mp<FP, K, K - 8, 8>(acc, m);
@@ -161,6 +169,49 @@ H2_HD void columns(int64_t& acc, const int32_t* a, const int32_t* b, int32_t* m,
     }
     acc >>= 29;                                                               // arithmetic: exact below K = 9
     columns<FP, K + 1>(acc, a, b, m, t);
+  }
+}
+// column K of a^2: cross terms with the doubled operand, the square of the middle limb once
+template <class FP, int K, int I, int IEND>
+H2_HD void col_sq(int64_t& acc, const int32_t* a, const int32_t* a2) {
+  if constexpr (I <= IEND) {
+    if constexpr (I < K - I) acc += (int64_t)a[I] * a2[K - I];
+    else if constexpr (I == K - I) acc += (int64_t)a[I] * a[I];
+    col_sq<FP, K, I + 1, IEND>(acc, a, a2);
+  }
+}
+template <class FP, int K>
+H2_HD void columns_sq(int64_t& acc, const int32_t* a, const int32_t* a2, int32_t* m, int32_t* t) {
+  if constexpr (K < 17) {
+    col_sq<FP, K, (K < 9 ? 0 : K - 8), K / 2>(acc, a, a2);
+    if constexpr (K < 9) {
+      if constexpr (K > 0) col_mp<FP, K, 0, K - 1>(acc, m);
+      m[K] = mont_m<FP>((uint32_t)acc);
+      mac_p<FP, 0>(acc, m[K]);
+    } else {
+      col_mp<FP, K, K - 8, 8>(acc, m);
+      t[K - 9] = (int32_t)((uint32_t)acc & L29_MASK);
+    }
+    acc >>= 29;
+    columns_sq<FP, K + 1>(acc, a, a2, m, t);
+  }
+}
+// column K of a b + c d
+template <class FP, int K>
+H2_HD void columns2(int64_t& acc, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, int32_t* m, int32_t* t) {
+  if constexpr (K < 17) {
+    col_ab<FP, K, (K < 9 ? 0 : K - 8), (K < 9 ? K : 8)>(acc, a, b);
+    col_ab<FP, K, (K < 9 ? 0 : K - 8), (K < 9 ? K : 8)>(acc, c, d);
+    if constexpr (K < 9) {
+      if constexpr (K > 0) col_mp<FP, K, 0, K - 1>(acc, m);
+      m[K] = mont_m<FP>((uint32_t)acc);
+      mac_p<FP, 0>(acc, m[K]);
+    } else {
+      col_mp<FP, K, K - 8, 8>(acc, m);
+      t[K - 9] = (int32_t)((uint32_t)acc & L29_MASK);
+    }
+    acc >>= 29;
+    columns2<FP, K + 1>(acc, a, b, c, d, m, t);
   }
 }
 }  // namespace detail29
@@ -175,9 +226,33 @@ H2_HD Fe29<FP> fe29_mul(const Fe29<FP>& a, const Fe29<FP>& b) {
   r.v[8] = (int32_t)acc;
   return r;
 }
+// a^2 / R': the cross terms a_i a_j (i < j) once, against the doubled limbs 2 a_j -- 45 limb products instead of 81.
+// Needs |a_i| < 2^29 (what fe29_mul(a, a) needs): a column is at most four cross terms below 2^59, one square below
+// 2^58 and nine m p terms below 2^58, under 2^63.
 template <class FP>
 H2_HD Fe29<FP> fe29_sqr(const Fe29<FP>& a) {
-  return fe29_mul(a, a);
+  int64_t acc = 0;
+  int32_t m[9], a2[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) a2[i] = a.v[i] * 2;
+  Fe29<FP> r;
+  detail29::columns_sq<FP, 0>(acc, a.v, a2, m, r.v);
+  r.v[8] = (int32_t)acc;
+  return r;
+}
+// (a b - c d) / R' with ONE reduction: both products are accumulated column by column before m is chosen (saves the 9 k
+// multiply-adds and the carry chain of a second reduction).  Needs every limb below 2^29 in magnitude: a column is at
+// most 18 limb products and nine m p terms below 2^58 each, under 2^63; |a b - c d| <= 64 p^2 as for a single product.
+template <class FP>
+H2_HD Fe29<FP> fe29_mul_sub(const Fe29<FP>& a, const Fe29<FP>& b, const Fe29<FP>& c, const Fe29<FP>& d) {
+  int64_t acc = 0;
+  int32_t m[9], nc[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) nc[i] = -c.v[i];
+  Fe29<FP> r;
+  detail29::columns2<FP, 0>(acc, a.v, b.v, nc, d.v, m, r.v);
+  r.v[8] = (int32_t)acc;
+  return r;
 }
 
 // API form (x 2^256 mod p, canonical) -> working form (x 2^261 mod p, canonical, normalised limbs)

@@ -65,6 +65,7 @@ struct MsmGeom {
   uint32_t W;        // windows
   uint32_t B;        // buckets per column = 2^(c-1)
   uint32_t nbits;    // scalar field bits
+  uint32_t wbase, wextra;          // window w has wbase + (w < wextra) bits and starts where window w - 1 ends
   uint8_t off[MSM_MAX_WINDOWS];    // first bit of window w
   uint8_t width[MSM_MAX_WINDOWS];  // bits of window w (c or c-1)
 };
@@ -84,6 +85,8 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
   const uint32_t total = nbits + 1;  // one spare bit: the top window never carries out
   g.W = (total + c - 1) / c;
   const uint32_t base = total / g.W, extra = total % g.W;
+  g.wbase = base;
+  g.wextra = extra;
   uint32_t o = 0;
   for (uint32_t w = 0; w < g.W; w++) {
     g.off[w] = (uint8_t)o;
@@ -216,6 +219,35 @@ H2_HD uint32_t msm_digit_step(const uint32_t v[8], const MsmGeom& g, uint32_t w,
   return raw;
 }
 
+// The same digits taken IN ORDER from a scalar that is shifted down window by window: the windows are consecutive
+// (off_(w+1) = off_w + width_w) and their widths are base + 1 for the first `extra` windows, base for the rest, so no
+// table is indexed and no register is addressed dynamically (msm_digit_step's v[bit >> 5] put the scalar in scratch
+// memory: two scratch loads per digit, ~3 us per million entries in every sort kernel).
+struct MsmDigits {
+  uint32_t v[8];
+  uint32_t carry;
+  H2_HD explicit MsmDigits(const uint32_t s[8]) : carry(0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = s[i];
+  }
+  // window w's digit (0, or |d| | sign << 31); call with w = 0, 1, ..., W - 1 in turn
+  H2_HD uint32_t next(const MsmGeom& g, uint32_t w) {
+    const uint32_t width = g.wbase + (w < g.wextra ? 1u : 0u);          // 1 <= width <= 16
+    const uint32_t mask = (1u << width) - 1, halfw = 1u << (width - 1);
+    const uint32_t raw = (v[0] & mask) + carry;
+#pragma unroll
+    for (int i = 0; i < 7; i++) v[i] = (v[i] >> width) | (v[i + 1] << (32 - width));
+    v[7] >>= width;
+    if (raw > halfw) {
+      carry = 1;
+      const uint32_t mag = (1u << width) - raw;
+      return mag ? (mag | MSM_SIGN) : 0u;
+    }
+    carry = 0;
+    return raw;
+  }
+};
+
 // Workgroups are handed to the 8 XCDs round-robin by linear block id, and every XCD has an L2 of its own.  The sort's
 // two kernels therefore give XCD x a CONTIGUOUS range of (column, tile) pairs and a counter set of its own:
 //     group x = blockIdx.x % 8,   virtual id v = x * per + blockIdx.x / 8   (per = ceil(total / 8)),
@@ -252,6 +284,7 @@ inline uint32_t msm_tile_grid(uint32_t tiles, uint32_t m) {
 }
 
 }  // namespace h2
+#include "h2_tune.hpp"
 #include "h2_msm_sort2.hpp"
 namespace h2 {
 
@@ -274,10 +307,9 @@ msm_digits_kernel(const U128* __restrict__ scalars, uint32_t* __restrict__ gcoun
   __syncthreads();
   const uint32_t lo = id.tile * tile, hi = min(lo + tile, n);
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
-    uint32_t carry = 0;
+    MsmDigits dg(fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i))).v);
     for (uint32_t w = 0; w < g.W; w++) {
-      const uint32_t enc = msm_digit_step(s.v, g, w, carry);
+      const uint32_t enc = dg.next(g, w);
       if (enc) atomicAdd(&hist[(enc & ~MSM_SIGN) - 1], 1u);
     }
   }
@@ -447,10 +479,9 @@ msm_scatter_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict_
   const uint32_t lo = id.tile * tile, hi = min(lo + tile, n);
   // the digits are recomputed rather than stored by the first kernel: 32 bytes of scalar instead of 4 W bytes of digits
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    Fe<S> s = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
-    uint32_t carry = 0;
+    MsmDigits dg(fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i))).v);
     for (uint32_t w = 0; w < g.W; w++) {
-      const uint32_t enc = msm_digit_step(s.v, g, w, carry);
+      const uint32_t enc = dg.next(g, w);
       if (enc) {
         const uint32_t pos = atomicAdd(&hist[(enc & ~MSM_SIGN) - 1], 1u);
         sorted_ref[pos] = (w * n_bases + i) | (enc & MSM_SIGN);
@@ -513,10 +544,9 @@ msm_scatter_staged_kernel(const U128* __restrict__ scalars, const uint32_t* __re
   __syncthreads();
   const uint32_t lo = id.tile * tile, hi = min(lo + tile, n);
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    Fe<S> sc = fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i)));
-    uint32_t carry = 0;
+    MsmDigits dg(fe_from_mont(fe_load<S>(scalars + 2 * (col_stride * col + i))).v);
     for (uint32_t w = 0; w < g.W; w++) {
-      const uint32_t enc = msm_digit_step(sc.v, g, w, carry);
+      const uint32_t enc = dg.next(g, w);
       if (enc) {
         const uint32_t b = (enc & ~MSM_SIGN) - 1;
         const uint32_t pos = atomicAdd(&cur[b], 1u);
@@ -556,7 +586,7 @@ __device__ __forceinline__ Affine29<CV> msm_fetch(const U128* __restrict__ table
 // length (a proof's permutation products over g_lagrange and its random polynomial over g share a launch); the
 // column of a key is key >> log_b.  Null: every column uses `table`.
 template <class CV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MSM_CHUNK_WAVES)
 msm_chunk_kernel(const U128* __restrict__ table, const U128* const* __restrict__ col_tables, uint32_t log_b,
                  const uint32_t* __restrict__ sorted_ref,
                  const uint32_t* __restrict__ chunk_first, const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host,
@@ -783,6 +813,14 @@ msm_fixup_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host
 // the row family is applied HERE, by lb doublings of every row sum (and of the last column's sum, whose multiplier
 // cols = 2^lb * 1 is the one that does not fit lb bits): the row waves have fewer points to add than the column waves
 // when hb > lb, and a doubling done by 2^hb waves side by side is off the final kernel's one chain.
+// The last column's multiplier is cols = 2^lb, one bit more than the column family's digits hold, so it rides in the row
+// family (item 0, whose own multiplier would be 0).  If 2^lb fits the ROW family's base-4 digits (hb odd, or hb > lb) it
+// is simply that item's multiplier; otherwise msm_rowcol_kernel doubles that sum lb times like a row and the multiplier
+// is 1.
+H2_HD bool msm_special_predoubled(uint32_t log_b, uint32_t lb) {
+  const uint32_t hb = log_b - lb, ndig = ((hb + 1) >> 1) ? ((hb + 1) >> 1) : 1u;
+  return lb >= 2 * ndig;
+}
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, uint32_t* __restrict__ done,
@@ -799,8 +837,15 @@ msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, 
   const uint32_t quad = threadIdx.x >> 2, nq = blockDim.x >> 2, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // the first point is taken as it is: an addition onto the identity costs as much as any other
   Xyzz29<CV> a = quad < len ? xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + quad * stride)) : Xyzz29<CV>::identity();
-  for (uint32_t j = quad + nq; j < len; j += nq)
-    a = xyzz29_add_quad(a, xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + j * stride)));
+  if (quad + nq < len) {
+    // the next point is on its way while the current one is added (144 bytes from L2 / HBM: the chain has nothing else to do)
+    Xyzz29<CV> nxt = xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + (quad + nq) * stride));
+    for (uint32_t j = quad + nq; j < len; j += nq) {
+      const Xyzz29<CV> cur = nxt;
+      if (j + nq < len) nxt = xyzz29_load<CV>(base + XYZZ29_WORDS * (size_t)(first + (j + nq) * stride));
+      a = xyzz29_add_quad(a, cur);
+    }
+  }
   for (uint32_t d = 32; d >= 4; d >>= 1) a = xyzz_fold_down(a, d, lane);
   if (blockDim.x > 64) {
     if (wave > 0 && lane == 0) xyzz29_store<CV>(xw[wave - 1], a);
@@ -810,7 +855,7 @@ msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, 
     if (quad >= 1) a = quad < nw ? xyzz29_load<CV>(xw[quad - 1]) : Xyzz29<CV>::identity();
     for (uint32_t d = 2 * nw; d >= 4; d >>= 1) a = xyzz_fold_down(a, d, lane);
   }
-  if (is_row || blockIdx.x == rows + cols - 1)
+  if (is_row || (blockIdx.x == rows + cols - 1 && msm_special_predoubled(log_b, lb)))
     for (uint32_t k = 0; k < lb; k++) a = xyzz29_double_quad(a);
   if (threadIdx.x == 0) xyzz29_store<CV>(rc + XYZZ29_WORDS * ((size_t)col * (rows + cols) + blockIdx.x), a);
 }
@@ -843,8 +888,10 @@ __device__ __forceinline__ Xyzz29<CV> xyzz29_pick(uint32_t dig, const Xyzz29<CV>
 // 4-lanes-per-point arithmetic keeps a SIMD's issue port busy with ONE wave), ONE item per quad, so the chain is as
 // long as one multiplication whatever the bucket count (with a fixed eight blocks a 2^20-term MSM -- 256 + 127 items --
 // went round four times: 205 us):
-//     row family     blocks [0, ceil(rows / 16)):   item 0 = the last column's sum with multiplier 1 (rc holds it times
-//                    2^lb: its multiplier cols = 2^lb * 1; the rows' own item 0 would have multiplier 0),
+//     row family     blocks [0, ceil(rows / 16)):   item 0 = the last column's sum, whose multiplier cols = 2^lb does not
+//                    fit the column family's lb bits (the rows' own item 0 would have multiplier 0): multiplier 2^lb
+//                    where the row digits hold it, else 1 on a sum msm_rowcol_kernel has doubled lb times
+//                    (msm_special_predoubled),
 //                    item hi = 2^lb R_hi with multiplier hi                                    (< 2^hb)
 //     column family  the blocks behind them:        item lo = C_lo with multiplier lo + 1, lo < cols - 1   (< 2^lb)
 // multiplied two bits at a time (x, 2x, 3x, then per digit two doublings and one addition of the quad's own choice),
@@ -881,7 +928,7 @@ msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x MSM_FINA
   if (i < cnt) {
     const uint32_t idx = fam ? rows + i : (i == 0 ? rows + cols - 1 : i);
     x = xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)idx);
-    k = fam ? i + 1 : (i == 0 ? 1u : i);
+    k = fam ? i + 1 : (i == 0 ? (msm_special_predoubled(log_b, lb) ? 1u : cols) : i);
   }
   P r = x;
   H2_STAMP(0);
@@ -1149,7 +1196,7 @@ struct MsmWorkspace {
   uint32_t rc;          // row + column sums per column = 2^(log_b - lb) + 2^lb
   size_t off_counts, off_gcounts, off_offsets, off_tile_base, off_tile_hist, off_blocksums, off_ref, off_key, off_misc, off_bsum,
       off_head, off_tail, off_xsum, off_rc, off_part, off_done, off_tree2, off_hot_slot, off_hot_tasks, off_hot_part, total;
-  size_t off_cstart, off_mid_ref, off_mid_lo;   // two-level sort only
+  size_t off_cstart, off_group_base, off_mid_ref, off_mid_lo;   // two-level sort only
   size_t zero_bytes;    // misc + the counters behind it: cleared by one memset per launch
   uint32_t max_tasks;
   uint32_t guard;       // bytes of red zone behind every region (0 in the product path)
@@ -1168,7 +1215,9 @@ inline bool msm_use_sort2(size_t n, size_t m, const MsmGeom& g) {
   return fits && g.B > 4096;
 }
 
-inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g, uint32_t guard = 0) {
+inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g, uint32_t guard = 0, size_t n_bases = 0,
+                                  bool allow_pack = true) {
+  if (!n_bases) n_bases = n;
   MsmWorkspace ws{};
   ws.n = n;
   ws.m = m;
@@ -1211,7 +1260,7 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g, uint32_t
   uint32_t lg = lq + 2;
   ws.log_g = lg;
   ws.sort2 = msm_use_sort2(n, m, g) ? 1u : 0u;
-  ws.s2 = msm_sort2_geom(n, g);
+  ws.s2 = msm_sort2_geom(n, g, allow_pack ? n_bases : 0);
   // digits / scatter tiling: about 1024 blocks over the launch, at least one wave of scalars per block
   size_t tile = (n * m + 1023) / 1024;
   // a tile should carry a few entries per bucket, or zeroing / flushing the LDS histogram dominates
@@ -1267,8 +1316,9 @@ inline MsmWorkspace msm_workspace(size_t n, size_t m, const MsmGeom& g, uint32_t
     ws.off_offsets = region("offsets", (ws.K + 1) * 4);
     ws.off_tile_base = region("tile bases", t2 * ws.s2.Hc * 4);
     ws.off_tile_hist = region("tile counts", t2 * ws.s2.Hc * 4);
+    ws.off_group_base = region("group bases", (size_t)ws.s2.groups * m * ws.s2.Hc * 4);
     ws.off_mid_ref = region("coarse-sorted entries", ws.E * 4);
-    ws.off_mid_lo = region("coarse-sorted low key bits", ws.E);
+    ws.off_mid_lo = region("coarse-sorted low key bits", ws.s2.pack_shift ? 0 : ws.E);
     ws.off_blocksums = ws.off_cstart;     // unused
   } else {
     // misc (256 B), per-key totals (only the multi-kernel scan reads them), the per-XCD-group counters
@@ -1341,8 +1391,10 @@ inline const char* msm_check(const MsmWorkspace& ws, const MsmGeom& g, size_t n,
     MSM_REQUIRE(bytes_at(ws.off_cstart) >= (H + 1) * 4);
     MSM_REQUIRE(bytes_at(ws.off_tile_base) >= (size_t)s.tiles * m * s.Hc * 4);
     MSM_REQUIRE(bytes_at(ws.off_tile_hist) >= (size_t)s.tiles * m * s.Hc * 4);
-    MSM_REQUIRE(bytes_at(ws.off_mid_ref) >= ws.E * 4 && bytes_at(ws.off_mid_lo) >= ws.E);
-    MSM_REQUIRE((size_t)s.Hc * 4 <= 64 * 1024);
+    MSM_REQUIRE(bytes_at(ws.off_mid_ref) >= ws.E * 4 && (s.pack_shift || bytes_at(ws.off_mid_lo) >= ws.E));
+    MSM_REQUIRE(s.group >= 1 && s.group <= S2_GROUP && (size_t)s.groups * s.group >= s.tiles && bytes_at(ws.off_group_base) >= (size_t)s.groups * m * s.Hc * 4);
+    MSM_REQUIRE(!s.pack_shift || (((uint64_t)g.W * n_bases <= (1ull << s.pack_shift)) && s.pack_shift + s.lo_bits <= 31));
+    MSM_REQUIRE((size_t)s.Hc * 8 <= 64 * 1024);
     MSM_REQUIRE(msm_sort2_lds_scatter(s, g) <= 160 * 1024 - 512 && msm_sort2_lds_fine() + 4 * S2_MAX_F * 4 <= 160 * 1024 - 512);
   } else {
     const size_t tiles = (n + ws.tile - 1) / ws.tile;
@@ -1448,13 +1500,14 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
     uint32_t* cstart = (uint32_t*)(ws_base + ws.off_cstart);
     uint32_t* mid_ref = (uint32_t*)(ws_base + ws.off_mid_ref);
     uint8_t* mid_lo = (uint8_t*)(ws_base + ws.off_mid_lo);
-    hipLaunchKernelGGL(msm2_count_kernel<CV>, dim3(s2.tiles, (unsigned)m), dim3(S2_THREADS), (size_t)s2.Hc * 4, stream, d_scalars,
-                       gcounts, tile_base, tile_hist, (uint32_t)n, col_stride, s2, g);
+    uint32_t* group_base = (uint32_t*)(ws_base + ws.off_group_base);
+    hipLaunchKernelGGL(msm2_count_kernel<CV>, dim3(s2.groups, (unsigned)m), dim3(S2_THREADS), (size_t)s2.Hc * 8, stream, d_scalars,
+                       gcounts, tile_base, tile_hist, group_base, (uint32_t)n, col_stride, s2, g);
     hipLaunchKernelGGL(msm2_coarse_scan_kernel, dim3(1), dim3(1024), 0, stream, gcounts, cstart, H, offsets + ws.K);
     hipLaunchKernelGGL(msm2_scatter_kernel<CV>, dim3(s2.tiles, (unsigned)m), dim3(S2_THREADS), msm_sort2_lds_scatter(s2, g), stream,
-                       d_scalars, cstart, tile_base, tile_hist, mid_ref, mid_lo, (uint32_t)n, col_stride, n_bases, s2, g);
+                       d_scalars, cstart, tile_base, tile_hist, group_base, mid_ref, mid_lo, (uint32_t)n, col_stride, n_bases, s2, g);
     hipLaunchKernelGGL(msm2_fine_kernel, dim3(H), dim3(S2_THREADS), msm_sort2_lds_fine(), stream, cstart, mid_ref, mid_lo, sref,
-                       offsets, s2.F, s2.lo_bits);
+                       offsets, s2.F, s2.lo_bits, s2.pack_shift);
   } else {
     const size_t lds = (size_t)g.B * 4;     // dynamic LDS limits were raised once per device by msm_kernel_setup
     const uint32_t tiles = (uint32_t)((n + ws.tile - 1) / ws.tile);

@@ -47,7 +47,8 @@ int h2_selftest_set_msm_max_entries(uint64_t limit);
  *   live pairs and every surplus block of the rounded-up grid is dead.
  * h2_selftest_msm_guard(1): from now on every MSM launch lays its arena out with a 256-byte red zone behind every
  *   region, fills the arena with a pattern first and counts the red-zone bytes that changed afterwards (synchronous;
- *   tests only; guard(2) also writes one byte behind the second region itself, to test the checker).
+ *   tests only; guard(2) also writes one byte behind the second region itself, to test the checker; guard(3) also makes
+ *   the two-level sort carry the key's low bits in its side array, the layout of SRS sizes whose entries have no spare bits).
  *   h2_selftest_msm_guard_report: out[0] = launches checked, out[1] = regions overrun since guard(1);
  *   `first` = a description of the first one. */
 int h2_selftest_msm_check(int curve, size_t n_bases, size_t n, size_t m, size_t col_stride, int guard, uint64_t out[8]);

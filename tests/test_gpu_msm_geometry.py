@@ -80,6 +80,26 @@ def test_awkward_shapes_stay_inside_their_regions(h2, guarded, curve, n_bases, n
         bases.release()
 
 
+def test_two_level_sort_with_the_side_array(h2, guarded):
+    """at 2^24 bases an entry (w * n + i | sign) has no spare bits for the key's low bits, which then travel in a byte
+    array; guard(3) selects that layout at 2^18"""
+    lib = guarded
+    lib.h2_selftest_msm_guard(3)
+    curve, n = "pallas", 1 << 18
+    b = bases_of(curve, n)
+    bases = h2.Bases(curve, b)
+    try:
+        cols = [scalars(curve, n, 60 + j) for j in range(2)]
+        cols[1][::2] = 0
+        got = bases.msm_batch(cols)
+        launches, violations, first = guard_report(lib)
+        assert launches >= 1 and violations == 0, first
+        for j, col in enumerate(cols):
+            assert np.array_equal(got[j], O.to_affine(CID[curve], O.best_multiexp(CID[curve], col, b, threads=8))), j
+    finally:
+        bases.release()
+
+
 def test_two_level_sort_on_skewed_columns(h2, guarded):
     """coarse bins far from uniform: a constant column (every entry of a window in ONE bucket: bins of 2^18 entries, many
     slabs per level-2 block), a 0/1 selector, a sparse column, and a dense one, 2^18 rows each"""
