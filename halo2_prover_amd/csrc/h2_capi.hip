@@ -294,9 +294,11 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
 }
 
 // ---- NTT -----------------------------------------------------------------------------------
-static int get_twiddles(DevCtx& c, const CurveOps* ops, const uint64_t omega[4], uint32_t log_n, const void** out) {
+static int get_twiddles(DevCtx& c, const CurveOps* ops, const uint64_t omega[4], uint32_t log_n, const uint64_t* scale,
+                        const void** out) {
   for (auto& t : c.twiddles) {
-    if (t.field == ops->scalar_field_id && t.log_n == log_n && memcmp(t.omega, omega, 32) == 0) {
+    if (t.field == ops->scalar_field_id && t.log_n == log_n && memcmp(t.omega, omega, 32) == 0 && t.scaled == (scale != nullptr) &&
+        (!scale || memcmp(t.scale, scale, 32) == 0)) {
       t.stamp = ++c.stamp;
       *out = t.tw;
       return H2_OK;
@@ -314,19 +316,20 @@ static int get_twiddles(DevCtx& c, const CurveOps* ops, const uint64_t omega[4],
   te.field = ops->scalar_field_id;
   te.log_n = log_n;
   memcpy(te.omega, omega, 32);
-  const size_t bytes = (((size_t)1 << log_n) / 2) * 32;
-  hipError_t e = hipMalloc(&te.tw, bytes < 64 ? 64 : bytes);
+  te.scaled = scale != nullptr;
+  if (scale) memcpy(te.scale, scale, 32);
+  hipError_t e = hipMalloc(&te.tw, ops->ntt_table_bytes(log_n));
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return H2_ENOMEM;
   }
   // built on the library's stream and finished before anybody uses it: a table is shared by every later caller,
-  // whatever stream they bring (once per (field, omega, log n))
-  e = ops->ntt_twiddles(te.tw, omega, log_n, c.stream);
+  // whatever stream they bring (once per (field, omega, log n, constant))
+  e = ops->ntt_twiddles(te.tw, omega, log_n, c.stream, scale);
   if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
   if (e != hipSuccess) {
     (void)hipFree(te.tw);
-    return dev_fail(e, "ntt_build_twiddles");
+    return dev_fail(e, "ntt_build_tables");
   }
   te.stamp = ++c.stamp;
   c.twiddles.push_back(te);
@@ -339,7 +342,8 @@ int ntt_enqueue(DevCtx& c, int curve, void* d_a, size_t m, const uint64_t omega[
   const CurveOps* ops = ops_of(curve);
   if (!ops) return H2_EINVAL;
   const void* tw = nullptr;
-  int rc = get_twiddles(c, ops, omega, log_n, &tw);
+  // a constant that rides in the inter-pass twiddles needs tables built with it
+  int rc = get_twiddles(c, ops, omega, log_n, (scale && ops->ntt_scale_in_table(log_n)) ? scale : nullptr, &tw);
   if (rc != H2_OK) return rc;
   NttPlan pl = ntt_make_plan(log_n);
   void* scratch = nullptr;

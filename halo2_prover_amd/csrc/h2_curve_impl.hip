@@ -25,15 +25,9 @@ using CV = VESTA_CURVE;
 using FS = typename CV::Scalar;
 using FB = typename CV::Base;
 
-// H2_TUNE_NTT32 (tuning builds only, h2_tune.hpp): the 32-bit-limb pass kernel of h2_ntt.hpp instead of the 29-bit one, for A/B timing
-bool ntt_use_32() {
-  static const bool v = tune_int("H2_TUNE_NTT32", 0) != 0;
-  return v;
-}
 hipError_t kernel_setup() {
   hipError_t e = msm_kernel_setup<CV>();
   if (e != hipSuccess) return e;
-  if ((e = ntt_kernel_setup<FS>()) != hipSuccess) return e;
   return ntt29_kernel_setup<FS>();
 }
 hipError_t table_build(const void* d_bases, void* d_table, void* d_scratch, uint32_t n, const MsmGeom& g, uint32_t* d_bad, hipStream_t s) {
@@ -88,18 +82,19 @@ hipError_t points_sum(const void* d_in_jac, void* d_out_jac, uint32_t groups, ui
                      (U128*)d_out_jac, groups, count);
   return hipGetLastError();
 }
-hipError_t ntt_twiddles(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s) {
-  Fe<FS> w;
+size_t ntt_table_bytes(uint32_t log_n) { return ntt29_tables(log_n).total; }
+bool ntt_scale_in_table(uint32_t log_n) { return ntt29_scale_in_table(log_n); }
+hipError_t ntt_twiddles(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s, const uint64_t* scale) {
+  Fe<FS> w, sc;
   memcpy(w.v, omega, 32);
-  if (ntt_use_32()) return ntt_build_twiddles<FS>((U128*)d_tw, w, log_n, s);
-  return ntt29_build_twiddles<FS>((U128*)d_tw, w, log_n, s);
+  if (scale) memcpy(sc.v, scale, 32);
+  return ntt29_build_tables<FS>(d_tw, w, log_n, s, scale ? &sc : nullptr);
 }
 hipError_t ntt_launch_(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m, hipStream_t s,
                        const uint64_t* scale) {
   Fe<FS> sc;
   if (scale) memcpy(sc.v, scale, 32);
-  if (ntt_use_32()) return ntt_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s, scale ? &sc : nullptr);
-  return ntt29_launch<FS>((U128*)d_data, (U128*)d_scratch, (const U128*)d_tw, log_n, m, s, scale ? &sc : nullptr);
+  return ntt29_launch<FS>((U128*)d_data, (U128*)d_scratch, d_tw, log_n, m, s, scale ? &sc : nullptr);
 }
 hipError_t poly_scale(void* d_a, size_t total, const uint64_t c[4], hipStream_t s) {
   Fe<FS> cv;
@@ -349,7 +344,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 }
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, kernel_setup, table_build, msm_launch_,    srs_powers, fixed_base_mul, msm_small,
-                      to_affine,   points_sum, ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
+                      to_affine,   points_sum, ntt_table_bytes, ntt_scale_in_table, ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
                       poly_pointwise, poly_inverse, poly_divide_linear, poly_prefix_product, chacha20_scalars, selftest_field, selftest_curve,
                       selftest_field_device, selftest_curve_device, selftest_digits, modmul_rate};
 

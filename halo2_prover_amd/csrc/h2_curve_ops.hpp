@@ -37,7 +37,12 @@ struct CurveOps {
   // d_out[j] = sum_g d_in[g * count + j], Jacobian points in the API form
   hipError_t (*points_sum)(const void* d_in_jac, void* d_out_jac, uint32_t groups, uint32_t count, hipStream_t s);
   // NTT over the scalar field
-  hipError_t (*ntt_twiddles)(void* d_tw, const uint64_t omega[4], uint32_t log_n, hipStream_t s);
+  // the tables of one (omega, log n [, constant]): inter-pass twiddles, unpacked radix twiddles per pass, the
+  // canonicalisation table (h2_ntt29.hpp).  ntt_scale_in_table: a transform scaled by a constant takes that constant
+  // from tables built with it (two-pass plans); otherwise the final pass multiplies
+  size_t (*ntt_table_bytes)(uint32_t log_n);
+  bool (*ntt_scale_in_table)(uint32_t log_n);
+  hipError_t (*ntt_twiddles)(void* d_tables, const uint64_t omega[4], uint32_t log_n, hipStream_t s, const uint64_t* scale /* or null */);
   hipError_t (*ntt_launch)(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m,
                            hipStream_t s, const uint64_t* scale /* 4 limbs or null */);
   // pointwise polynomial kernels over the scalar field (EvaluationDomain pieces)

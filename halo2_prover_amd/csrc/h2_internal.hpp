@@ -30,6 +30,8 @@ struct TwiddleEntry {
   int field;
   uint32_t log_n;
   uint64_t omega[4];
+  bool scaled;            // the inter-pass twiddles carry `scale` (a two-pass scaled transform)
+  uint64_t scale[4];
   void* tw;
   uint64_t stamp;
 };

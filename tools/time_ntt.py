@@ -23,4 +23,4 @@ for i in range(reps):
     ev[i + 1].record()
 torch.cuda.synchronize()
 ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
-print("ntt 2^%d x %d: median %.1f us  min %.1f us  (%s)" % (lg, m, ts[len(ts) // 2] * 1e3, ts[0] * 1e3, "32-bit" if os.environ.get("H2_TUNE_NTT32") else "29-bit"))
+print("ntt 2^%d x %d: median %.1f us  min %.1f us" % (lg, m, ts[len(ts) // 2] * 1e3, ts[0] * 1e3))
