@@ -15,12 +15,15 @@ section 8(a)/App. A.4), with dense synthetic columns already resident in HBM:
 
 value = field-ops/s with the reference-parameter yardstick of SURVEY.md section 8(d):
 ops_msm(n) = S*(11n + 32(2^c-1)) + 7*256 with c = ceil(ln n), S = 256/c+1;  ops_ntt(n) = 3*(n/2)*log2 n.
-With N > 1 every rank runs the step on its own columns (weak scaling; columns shard, nothing else
-does) and the per-step commitment vector is all-gathered once over RCCL.
+With N > 1 the SAME job is spread over the ranks (strong scaling): each MSM phase is sharded by whole columns when
+m % N == 0, else every rank takes a point range of every column; one all-gather of 96-byte points per phase over RCCL;
+NTT columns go j -> rank j mod N with no collective.
 
 Printed keys beyond the driver contract: "roofline" (bucket-accumulate kernel, HIP-event timed
 inside the library on the launch stream), "cpu_baseline" (the CPU oracle timed on this host,
-rank 0, N = 1 only), "phases_ms".
+rank 0, N = 1 only), "phases_ms", and the sub-records "bn254_step" (the same step on the curve whose parity is pinned
+by the reference's recorded outputs), "drop_in_step" (the same step through the host-pointer entry points a patched
+halo2_proofs would call, PCIe included), "headline_msm_2e20", "proof_gen".
 """
 import argparse
 import ctypes
@@ -461,11 +464,28 @@ def main():
         extras["headline_msm_2e20"] = headline_msm(args, 20, make_srs, world, rank, dev, stream, barrier, modmul, p, multi)
         if multi:
             extras["config5"] = config5(args, make_srs, world, rank, dev, stream, barrier, p, gen, two_adicity, R)
+        if world == 1 and not multi:
+            # sub-records on one GPU: the pinned curve, and the host-pointer route
+            if args.curve != "bn254":
+                extras["bn254_step"] = step_on_curve(args, "bn254", dev)
+            extras["drop_in_step"] = drop_in_step(args, args.curve)
 
     proof_gen = None
-    # every rank runs the prover (its commit phases contain the all-gather); rank 0 reports
-    if not args.no_proof and args.workload == "poseidon":
-        proof_gen = proof_generation(k, world)
+    # h2_generate_proof is one process on this rank's GPU(s): rank 0 runs and reports it; n_gpus in the record says what
+    # ran (the C++ prover shards its commit phases over the contexts of h2_init_devices, not over ranks)
+    proof_gen_multi = None
+    if not args.no_proof and args.workload == "poseidon" and rank == 0:
+        proof_gen = proof_generation(k)
+    if not args.no_proof and args.workload == "poseidon" and world > 1 and ndev >= world:
+        # the N-GPU proof: ONE process with N contexts (h2_init_devices), started by rank 0 while the other ranks wait at
+        # the barrier below with their GPUs idle; its commit phases are split by point range over the N GPUs
+        if rank == 0:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "proof_bench.py"), str(k), str(world)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            proof_gen_multi = json.loads(line[-1]) if r.returncode == 0 and line else {"error": r.stderr[-400:]}
+        barrier()
 
     if rank == 0:
         workload = {"poseidon": "poseidon_k%d_proof_shape: 16 MSM(2^%d) in launches m=4,2+1,5,4 + 7 iNTT(2^%d) + "
@@ -483,7 +503,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_min": per_step[0],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit modular)",
-            "data": "synthetic (dense SplitMix64 scalars; bases [s^i]G made on the device)",
+            "data": "synthetic (dense SplitMix64 scalars as SURVEY 8(d) defines them; bases [s^i]G made on the device instead of "
+                    "8(d)'s try-and-increment points: the same cost per addition, a different distribution)",
             "parity": "bn254 pinned by the reference's recorded params / proofs; pallas and vesta self-consistent "
                       "(no reference vector exists)",
             "config": {"workload": workload, "curve": args.curve, "k": k, "columns": n_msm,
@@ -492,7 +513,7 @@ def main():
                        "msm_table_bytes": plan["table_bytes"]},
             "sharded_equals_unsharded": sharded_ok,
             "roofline": roofline, "roofline_ntt": roofline_ntt, "modmul_ceiling": modmul,
-            "cpu_baseline": cpu, "proof_gen": proof_gen,
+            "cpu_baseline": cpu, "proof_gen": proof_gen, "proof_gen_n_gpus": proof_gen_multi,
             "phases_ms": phases_ms, "overlap": overlap, "field_ops_per_step": ops_step,
         }
         out.update(extras)
@@ -511,6 +532,165 @@ def _device_scalars(L, cid, count, seed_byte, dev, stream):
     seed = bytes([seed_byte]) * 32
     h2lib.check(L.h2_chacha20_scalars_device(cid, seed, 0, count, t.data_ptr(), stream), "h2_chacha20_scalars_device")
     return t
+
+
+def step_on_curve(args, curve, dev, steps=10, warmup=2):
+    """The Poseidon k = 16 proof-shaped step on another curve, one GPU, as a sub-record: same launches (m = 4, 2 + 1, 5,
+    4), same transforms, same two streams as the headline step; timed with the contract's bracket."""
+    import torch
+    import halo2_prover_amd as h2
+    from halo2_prover_amd import lib as h2lib
+    from halo2_prover_amd import sharded
+    L = h2.load()
+    cid = h2.CURVES[curve]
+    fname, gen, two_adicity = SCALAR_FIELD[curve]
+    p = MODULI[fname]
+    R = (1 << 256) % p
+    k, ext = args.k, 3
+    n = 1 << k
+    work_stream = torch.cuda.current_stream()
+    stream = work_stream.cuda_stream
+    side_stream = torch.cuda.Stream(device=dev, priority=0)
+    side = side_stream.cuda_stream
+
+    def srs(sval):
+        buf = torch.empty((n, 8), dtype=torch.int64, device=dev)
+        h2lib.check(L.h2_srs_generate(cid, limbs(sval * R % p).ctypes.data, n, buf.data_ptr(), stream), "h2_srs_generate")
+        torch.cuda.synchronize()
+        b = h2.Bases.from_device(curve, buf.data_ptr(), n)
+        del buf
+        return b
+
+    def omega(log_n, inverse=False):
+        root = pow(gen, (p - 1) >> two_adicity, p)
+        w = pow(root, 1 << (two_adicity - log_n), p)
+        return limbs((pow(w, -1, p) if inverse else w) * R % p)
+
+    g_lagrange, g = srs(0x1234567), srs(0x7654321)
+    phases = [(g_lagrange, 4), ([g_lagrange, g_lagrange, g], 3), (g, 5), (g, 4)]
+    cols = torch.from_numpy(splitmix_columns(0x48324D5300000101, 16 * n, p).view(np.int64)).to(dev)
+    ntts = [("advice_i", k, 5, True), ("advice_e_a", k + ext, 2, False), ("advice_e_b", k + ext, 3, False),
+            ("z_i", k, 2, True), ("z_e", k + ext, 2, False), ("h_i", k + ext, 1, True)]
+    bufs = {name: (torch.from_numpy(splitmix_columns(0x48324D5300000110 + j, m << lg, p).view(np.int64)).to(dev), lg, m,
+                   omega(lg, inv)) for j, (name, lg, m, inv) in enumerate(ntts)}
+    ev_start, ev_side_done = torch.cuda.Event(), torch.cuda.Event()
+
+    def phase(i, off):
+        bases, m = phases[i]
+        sharded.msm_phase_device(bases, cols.data_ptr() + off * n * 32, n, m, stream, mode="single")
+        return off + m
+
+    def ntt(name, st):
+        buf, lg, m, w = bufs[name]
+        h2.ntt_device(buf.data_ptr(), m, w, lg, curve, st)
+
+    def step():
+        ev_start.record(work_stream)
+        side_stream.wait_event(ev_start)
+        off = phase(0, 0)
+        L.h2_stream_wait_msm_tail(side)
+        ntt("advice_i", side)
+        ntt("advice_e_a", side)
+        off = phase(1, off)
+        L.h2_stream_wait_msm_tail(side)
+        ntt("advice_e_b", side)
+        ntt("z_i", side)
+        ntt("z_e", side)
+        ev_side_done.record(side_stream)
+        work_stream.wait_event(ev_side_done)
+        ntt("h_i", stream)
+        off = phase(2, off)
+        phase(3, off)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    L.h2_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = h2lib.Profile()
+    h2lib.check(L.h2_profile_read(ctypes.byref(prof)), "h2_profile_read")
+    L.h2_profile_enable(0)
+    r3 = ctypes.c_double(0)
+    h2lib.check(L.h2_selftest_modmul_rate(cid, 3, 512, ctypes.byref(r3)), "h2_selftest_modmul_rate")
+    plan = g.plan()
+    ops_step = 16 * ops_msm(n) + sum(m * ops_ntt(1 << lg) for _, lg, m, _ in ntts)
+    mm = prof.algorithmic_bytes / 96.0 * plan["windows"] * 10 / (prof.kernel_ms * 1e-3)
+    rec = {"curve": curve, "workload": "the same step (16 MSM(2^%d) + 15 NTT) on %s" % (k, curve), "steps": steps,
+           "ms_per_step": round(dt / steps * 1e3, 4), "field_ops_per_s": ops_step * steps / dt,
+           "accumulate_kernel_ms": round(prof.kernel_ms / prof.launches, 5),
+           "accumulate_hbm_frac": round(prof.algorithmic_bytes / (prof.kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+           "modmul_ceiling_at_3_waves": r3.value, "modmul_frac": round(mm / r3.value, 4),
+           "parity": "pinned: params files, proofs and vk digests recorded from the reference's own build (tests/golden)"}
+    for b in (g, g_lagrange):
+        b.release()
+    del cols, bufs
+    torch.cuda.empty_cache()
+    return rec
+
+
+def drop_in_step(args, curve, steps=5):
+    """What a maintainer gets from INTEGRATION.md section 3 alone: the same 16 MSMs and 15 NTTs, one call each, through
+    the HOST-pointer entry points best_multiexp / best_fft would be patched to call (h2_msm, h2_ntt) on pageable host
+    columns -- H2D of every column, the launch sequence, D2H of the result, per call.  Wall clock."""
+    import halo2_prover_amd as h2
+    L = h2.load()
+    cid = h2.CURVES[curve]
+    fname, gen, two_adicity = SCALAR_FIELD[curve]
+    p = MODULI[fname]
+    R = (1 << 256) % p
+    k, ext = args.k, 3
+    n = 1 << k
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    buf = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    L.h2_srs_generate(cid, limbs(0x1234567 * R % p).ctypes.data, n, buf.data_ptr(), None)
+    torch.cuda.synchronize()
+    host_bases = buf.cpu().numpy().view(np.uint64)
+    del buf
+    bases = h2.Bases(curve, host_bases)               # h2_bases_register: once per SRS, as the shim does
+    root = pow(gen, (p - 1) >> two_adicity, p)
+
+    def omega(lg):
+        return limbs(pow(root, 1 << (two_adicity - lg), p) * R % p)
+
+    cols = [splitmix_columns(0x48324D5300000201 + j, n, p) for j in range(16)]
+    small = [splitmix_columns(0x48324D5300000221 + j, n, p) for j in range(7)]
+    big = [splitmix_columns(0x48324D5300000231 + j, n << ext, p) for j in range(8)]
+    out = np.zeros(12, dtype=np.uint64)
+
+    def step():
+        for c in cols:
+            L.h2_msm(cid, bases.handle, c.ctypes.data, n, out.ctypes.data)
+        for a in small:
+            L.h2_ntt(cid, a.ctypes.data, omega(k).ctypes.data, k)
+        for a in big:
+            L.h2_ntt(cid, a.ctypes.data, omega(k + ext).ctypes.data, k + ext)
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    t1 = time.perf_counter()
+    for c in cols:
+        L.h2_msm(cid, bases.handle, c.ctypes.data, n, out.ctypes.data)
+    t_msm = (time.perf_counter() - t1) / 16
+    t2 = time.perf_counter()
+    for a in big:
+        L.h2_ntt(cid, a.ctypes.data, omega(k + ext).ctypes.data, k + ext)
+    t_big = (time.perf_counter() - t2) / 8
+    ops_step = 16 * ops_msm(n) + 7 * ops_ntt(n) + 8 * ops_ntt(n << ext)
+    bases.release()
+    return {"curve": curve, "through": "h2_msm x 16 + h2_ntt x 15 on pageable host columns (INTEGRATION.md section 3)",
+            "ms_per_step": round(dt * 1e3, 3), "field_ops_per_s": ops_step / dt,
+            "h2_msm_2e%d_ms" % k: round(t_msm * 1e3, 3), "h2_ntt_2e%d_ms" % (k + ext): round(t_big * 1e3, 3),
+            "bytes_over_pcie_per_step": 16 * n * 32 + 16 * 96 + 2 * 32 * (7 * n + 8 * (n << ext)),
+            "note": "every call uploads its column, runs one launch sequence and downloads the result; the resident step "
+                    "(value) keeps columns in HBM and batches the columns of a phase into one launch"}
 
 
 def headline_msm(args, lg, make_srs, world, rank, dev, stream, barrier, modmul, p, multi=False):
@@ -651,7 +831,7 @@ REFERENCE_PROOF_SHA256 = {6: "6d235bf4637e1dce12559c44eaf77812bae2746d78331db385
                           16: "4c4e7d9301b652969a92718b3183f0bda79be2aaab245b68033ca96bf27bdc3c"}
 
 
-def proof_generation(k, world=1):
+def proof_generation(k):
     """proof-gen ms of the metric: the reference's wasm_generate_proof path (ParamsKZG::read + keygen + create_proof,
     KZG/GWC over BN254) for the Poseidon circuit at 2^k rows, through the C ABI's product surface (h2_setup /
     h2_generate_proof / h2_verify_proof: C++ orchestration, every column resident in HBM), under the recorded RNG stream
@@ -730,7 +910,7 @@ def proof_generation(k, world=1):
         mirror.append((time.perf_counter() - ta, hashlib.sha256(pproof).hexdigest()))
         del pk
     del pparams
-    return {"circuit": "poseidon (bn254, KZG/GWC)", "k": k, "n_gpus": world, "through": "C ABI: h2_generate_proof",
+    return {"circuit": "poseidon (bn254, KZG/GWC)", "k": k, "n_gpus": int(L.h2_device_count()), "through": "C ABI: h2_generate_proof",
             "setup_ms": round((t1 - t0) * 1e3, 1),
             "proof_gen_ms": round(min(runs[1][0], runs[2][0]) * 1e3, 2),
             "create_proof_ms": round(min(runs[5][0], runs[6][0]) * 1e3, 2),
@@ -763,7 +943,7 @@ def cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    threads = max(1, min(cores, 64))
+    threads = max(1, cores)                              # T = hardware_concurrency(); T = 64 and T = 1 beside it
     if args.workload == "ntt":
         n_m = 0
     elif args.workload == "poseidon":
@@ -808,6 +988,17 @@ def cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R):
         t_single = time.perf_counter() - t2
         single = {"value": (ops_msm(n) + ops_ntt(n) + ops_ntt(n << ext)) / t_single, "unit": "field-ops/s", "cores": 1,
                   "sample": "1 MSM(2^%d) + 1 NTT(2^%d) + 1 NTT(2^%d): %.2f s" % (k, k, k + ext, t_single)}
+    at_64 = None
+    if args.workload == "poseidon" and threads > 64:
+        t3 = time.perf_counter()
+        for j in range(4):
+            O.best_multiexp(cid, cols_np[(j % ncols) * n:((j % ncols) + 1) * n], bases, threads=64)
+        a64 = cols_np[:n].copy()
+        O.best_fft(fid, a64, om(k), k, threads=64)
+        O.best_fft(fid, big, om(k + ext), k + ext, threads=64)
+        t64 = time.perf_counter() - t3
+        at_64 = {"value": (4 * ops_msm(n) + ops_ntt(n) + ops_ntt(n << ext)) / t64, "unit": "field-ops/s", "cores": 64,
+                 "sample": "4 MSM(2^%d) + 1 NTT(2^%d) + 1 NTT(2^%d): %.2f s" % (k, k, k + ext, t64)}
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -817,7 +1008,7 @@ def cpu_baseline(args, cols_np, n, k, ext, p, gen, two_adicity, R):
     except OSError:
         pass
     return {"value": work / total, "unit": "field-ops/s", "cores": threads, "kind": "port", "cpu_model": model,
-            "host_cores": cores, "single_thread": single,
+            "host_cores": cores, "single_thread": single, "at_64_threads": at_64,
             "sample": "%d MSM(2^%d)%s%s with %d threads: %.2f s" %
                       (n_m, k, " + %d NTT(2^%d)" % (4 if args.workload == "poseidon" else 1, k) if args.workload != "msm" else "",
                        " + 4 NTT(2^%d)" % (k + ext) if args.workload == "poseidon" else "", threads, total),

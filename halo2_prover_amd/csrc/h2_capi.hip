@@ -472,6 +472,7 @@ int h2_shutdown(void) {
       (void)hipEventDestroy(pe.first);
       (void)hipEventDestroy(pe.second);
     }
+    if (c.shard_ev) (void)hipEventDestroy(c.shard_ev);
     if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
     for (auto& e : c.side_ev)
       if (e) (void)hipEventDestroy(e);

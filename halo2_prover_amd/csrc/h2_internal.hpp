@@ -42,6 +42,7 @@ struct DevCtx {
   hipStream_t side_stream = nullptr;   // the C++ prover's second stream (transforms beside the MSM tails), created on demand
   hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
   Arena msm_ws, ntt_ws, stage, div_ws;
+  hipEvent_t shard_ev = nullptr;     // C++ prover: this context's share of a commit phase is done / the columns are final
   hipEvent_t tail_event = nullptr;   // recorded behind the accumulate kernel of the latest MSM (h2_stream_wait_msm_tail)
   bool tail_recorded = false, tail_wanted = false;   // the event costs ~5 us per MSM: recorded once somebody asked
   std::vector<TwiddleEntry> twiddles;

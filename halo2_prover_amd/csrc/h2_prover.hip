@@ -736,6 +736,15 @@ struct PendingCommit {
   void* out = nullptr;
   size_t m = 0;
 };
+// With several contexts (h2_init_devices) a commit phase is spread over them by POINT RANGE (SURVEY.md section 8(e),
+// as sharded.msm_phase_device does across ranks): context g commits rows / bases [n g / G, n (g+1) / G) of EVERY column
+// of the phase against its own replica of the table, so phases of m = 1 .. 5 columns use every GPU.  The other
+// contexts' shares of the columns travel device to device (peer copies, cnt * 32 bytes per column), their G x m partial
+// sums (96 bytes each) come back the same way and are added on the prover's device (points_sum_kernel): the same group
+// elements as the one-device commitment, hence the same proof bytes.  Transforms are NOT spread: a column would cross
+// xGMI twice (2 x 16 MiB for an extended column at k = 16, ~0.5 ms) for ~60 us of butterflies.
+uint64_t g_sharded_commits = 0;
+size_t g_shard_min_rows = 1024;            // per context; below this the copies and the extra launches cost more than they save
 PendingCommit commit_begin(Dev& d, const Params& P, Col cols, uint32_t n, size_t m, bool lagrange, size_t split = ~(size_t)0) {
   auto it = g_h2.bases.find(lagrange ? P.h_gl : P.h_g);
   if (it == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
@@ -743,15 +752,55 @@ PendingCommit commit_begin(Dev& d, const Params& P, Col cols, uint32_t n, size_t
   pc.m = m;
   pc.out = d.alloc(m * 96);
   d.c->tail_wanted = true;                   // the MSM records an event behind its accumulate kernel (Dev::wait_msm_tail)
+  std::vector<const BasesEntry*> per;
+  const BasesEntry* be = &it->second;
   if (split < m) {
     auto ig = g_h2.bases.find(P.h_g), il = g_h2.bases.find(P.h_gl);
     if (ig == g_h2.bases.end() || il == g_h2.bases.end()) fail(H2_EHANDLE, "params bases released");
-    std::vector<const BasesEntry*> per(m);
+    per.resize(m);
     for (size_t j = 0; j < m; j++) per[j] = j < split ? &il->second : &ig->second;
-    st_ok(msm_device_run(*d.c, H2_BN254, il->second, cols, 0, n, n, m, pc.out, false, d.s, per.data()), "msm_device_run");
-  } else {
-    st_ok(msm_device_run(*d.c, H2_BN254, it->second, cols, 0, n, n, m, pc.out, false, d.s), "msm_device_run");
+    be = &il->second;
   }
+  const BasesEntry* const* perp = per.empty() ? nullptr : per.data();
+  const size_t G = g_h2.ctx.size();
+  if (G == 1 || (size_t)n < g_shard_min_rows * G) {
+    st_ok(msm_device_run(*d.c, H2_BN254, *be, cols, 0, n, n, m, pc.out, false, d.s, perp), "msm_device_run");
+    return pc;
+  }
+  g_sharded_commits++;
+  const size_t self = ctx_index(d.c);
+  char* partials = (char*)d.alloc(G * m * 96);
+  auto event_of = [](DevCtx& c) {
+    if (!c.shard_ev) hip_ok(hipEventCreateWithFlags(&c.shard_ev, hipEventDisableTiming), "hipEventCreateWithFlags");
+    return c.shard_ev;
+  };
+  hip_ok(hipEventRecord(event_of(*d.c), d.s), "hipEventRecord");            // the columns are final from here on
+  size_t slot = 1;
+  for (size_t g = 0; g < G; g++) {
+    if (g == self) continue;
+    DevCtx& cg = g_h2.ctx[g];
+    DeviceGuard dg(cg.device);
+    const size_t lo = (size_t)n * slot / G, hi = (size_t)n * (slot + 1) / G, cnt = hi - lo;
+    const size_t res_off = (m * cnt * 32 + 255) & ~(size_t)255;
+    st_ok(arena_acquire(cg.stage, res_off + m * 96, cg.stream), "arena");
+    hip_ok(hipStreamWaitEvent(cg.stream, d.c->shard_ev, 0), "hipStreamWaitEvent");
+    for (size_t j = 0; j < m; j++)
+      hip_ok(hipMemcpyPeerAsync((char*)cg.stage.p + j * cnt * 32, cg.device, (const char*)cols + (j * (size_t)n + lo) * 32,
+                                d.c->device, cnt * 32, cg.stream), "hipMemcpyPeerAsync(columns)");
+    void* d_res = (char*)cg.stage.p + res_off;
+    st_ok(msm_device_run(cg, H2_BN254, *be, cg.stage.p, lo, cnt, cnt, m, d_res, false, cg.stream, perp), "msm_device_run");
+    hip_ok(hipMemcpyPeerAsync(partials + slot * m * 96, d.c->device, d_res, cg.device, m * 96, cg.stream),
+           "hipMemcpyPeerAsync(partials)");
+    hip_ok(hipEventRecord(event_of(cg), cg.stream), "hipEventRecord");
+    st_ok(arena_release(cg.stage, cg.stream), "arena");
+    slot++;
+  }
+  // this context's share: rows [0, n / G)
+  st_ok(msm_device_run(*d.c, H2_BN254, *be, cols, 0, (size_t)n / G, n, m, partials, false, d.s, perp), "msm_device_run");
+  for (size_t g = 0; g < G; g++)
+    if (g != self) hip_ok(hipStreamWaitEvent(d.s, g_h2.ctx[g].shard_ev, 0), "hipStreamWaitEvent");
+  hip_ok(d.ops->points_sum(partials, pc.out, (uint32_t)G, (uint32_t)m, d.s), "points_sum");
+  d.release(partials);
   return pc;
 }
 std::vector<G1> commit_finish(Dev& d, PendingCommit& pc) {
@@ -1937,7 +1986,9 @@ bool h2::Transcript::read_point(G1* p) {
   if (!Fq::from_le_bytes_canonical(b, &x)) return false;
   G1 g;
   if (inf || (x.is_zero() && sign == 0)) {
-    if (!x.is_zero()) return false;
+    // the reference's Blake2bRead::read_point absorbs the point through common_point, which refuses the point at
+    // infinity ("cannot write points at infinity to the transcript"): verify_proof returns Err for such a proof
+    return false;
   } else {
     const Fq y2 = x * x * x + Fq::from_u64(3);
     // q = 3 mod 4: a square root is y2^((q + 1) / 4)
@@ -2123,6 +2174,19 @@ void h2_prover_shutdown(void) {
 }
 
 // keep proving keys between calls (default) or rebuild them on every call as the reference does; returns the old setting
+// commit phases that were spread over more than one context since the library was loaded (tests)
+uint64_t h2_selftest_sharded_commits(void) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  return g_sharded_commits;
+}
+
+// test hook: rows per context from which a commit phase is spread over the contexts (0 restores the default)
+int h2_selftest_set_shard_min_rows(size_t rows) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  g_shard_min_rows = rows ? rows : 1024;
+  return H2_OK;
+}
+
 int h2_key_cache(int enable) {
   std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   const int old = g_key_cache ? 1 : 0;

@@ -82,6 +82,8 @@ SELFTEST_SYMBOLS = {
     "h2_selftest_set_msm_max_entries": (_I, [_U64]),
     "h2_selftest_modmul_rate": (_I, [_I, _I, _I, ctypes.POINTER(ctypes.c_double)]),
     "h2_selftest_host": (_I, [_I, _P, _Z, _P, _Z, ctypes.POINTER(_Z)]),
+    "h2_selftest_sharded_commits": (_U64, []),
+    "h2_selftest_set_shard_min_rows": (_I, [_Z]),
     "h2_selftest_msm_check": (_I, [_I, _Z, _Z, _Z, _Z, _I, _P]),
     "h2_selftest_msm_tiles": (_I, [_U32, _U32]),
     "h2_selftest_msm_guard": (_I, [_I]),

@@ -100,7 +100,7 @@ def _run(bases, d_cols, first, n, stride, cols, d_out, stream):
         bases.msm_device_range(d_cols, first, n, stride, len(cols), d_out, stream)
 
 
-def msm_phase_device(bases, d_cols, n, m, stream=0, group=None, mode=None, device=None):
+def msm_phase_device(bases, d_cols, n, m, stream=None, group=None, mode=None, device=None):
     """The m commitments of one proof phase on the GPUs of `group`: d_cols is a device pointer to m columns of n
     scalars (stride n), identical on every rank; returns an (m, 12) int64 CUDA tensor of Jacobian points, the same
     group elements on every rank, in column order.  `bases`: one Bases object, or a list of m (column j commits against
@@ -112,9 +112,23 @@ def msm_phase_device(bases, d_cols, n, m, stream=0, group=None, mode=None, devic
                (h2_points_sum_device) -- BASELINE config 4's split of a single MSM, applied to every column.
     Either way ONE collective per phase, m * 96 bytes per rank; scalars and bases never cross GPUs.
     `device` defaults to the current CUDA device (the CPU tests of the sharding logic pass "cpu" and a stand-in
-    `bases` object)."""
+    `bases` object).
+
+    Stream contract: everything this function does -- its tensors, the library's launches, the all-gather -- is ordered
+    on torch's CURRENT stream of that device.  `stream` is the raw handle of that stream (default: looked up); handing in
+    any other stream is refused, because the zero-fill of the local buffer, the collective and the copy-out are torch
+    operations on the current stream and would race with launches made elsewhere."""
     import torch
     import torch.distributed as dist
+    if device is None or torch.device(device).type == "cuda":
+        current = torch.cuda.current_stream(torch.device(device) if device is not None else None).cuda_stream
+        if stream is None:
+            stream = current
+        elif int(stream) != int(current):
+            raise ValueError("msm_phase_device: `stream` must be torch's current stream (run inside "
+                             "`with torch.cuda.stream(s)` and pass s.cuda_stream, or pass nothing)")
+    elif stream is None:
+        stream = 0
     have_group = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if have_group else 1
     rank = dist.get_rank(group) if have_group else 0

@@ -65,9 +65,8 @@ class _ReadTranscript:
         if x >= Q:
             raise VerifyError("point x not canonical")
         if inf or (x == 0 and sign == 0):
-            if x != 0:
-                raise VerifyError("bad identity encoding")
-            pt = None
+            # Blake2bRead::read_point -> common_point refuses the point at infinity: the reference rejects such a proof
+            raise VerifyError("point at infinity in the proof")
         else:
             y2 = (x * x * x + 3) % Q
             y = pow(y2, (Q + 1) // 4, Q)

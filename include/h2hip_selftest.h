@@ -67,6 +67,10 @@ int h2_selftest_modmul_rate(int curve, int waves_per_simd, int iters, double* mo
  * 5: pairing check e(P1, Q1) e(P2, Q2) == 1 on two pairs of 64 + 128 canonical bytes -> one byte;
  * 6: the quotient program of circuit in[0] as the prover compiles it -> six u32 (instructions, products, column reads,
  *    live-value slots, constants, inserted reductions) followed by the instructions (3 x u32 each: op_dst, a, b). */
+/* commit phases of the C++ prover / keygen that were spread over more than one context (h2_init_devices) so far */
+uint64_t h2_selftest_sharded_commits(void);
+/* rows per context from which the C++ prover spreads a commit phase over the contexts (default 1024; 0 restores it) */
+int h2_selftest_set_shard_min_rows(size_t rows);
 int h2_selftest_host(int what, const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* out_len);
 #ifdef __cplusplus
 }

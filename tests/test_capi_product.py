@@ -278,6 +278,13 @@ def test_c_verifier_accepts_the_recorded_proofs_and_rejects_corruptions(h2, lib)
         assert c_verify(lib, params, b"", js, idx) == (0, 0)
     p4 = golden("params_k4.bin")
     assert c_verify(lib, p4, golden("proof_arithmetic_k4.bin"), '{"x":6,"y":9,"constant":7,"z":2924}', 1) == (0, 0)
+    # a point at infinity in the proof: Blake2bRead::read_point -> common_point refuses it, the reference returns Err.
+    # Both encodings (x = 0 with the identity flag, and all 32 bytes zero), in place of a commitment and of an opening point
+    proof = golden("proof_arithmetic_k4.bin")
+    for at in (0, 64, len(proof) - 32):
+        for enc in (bytes(31) + b"\x80", bytes(32)):
+            bad = proof[:at] + enc + proof[at + 32:]
+            assert c_verify(lib, p4, bad, ARITH_INPUT, 1) == (0, 0), at
 
 
 @pytest.mark.gpu

@@ -58,7 +58,18 @@ def _phase_worker(rank, world, port, curve, n, m, mode, out_dir):
     cols = np.stack([O.synth_scalars(O.CURVE_SCALAR_FIELD[cid], SEED | (0x700 + j), n).reshape(n, 4) for j in range(m)])
     bases = h2.Bases(curve, b)
     d = torch.from_numpy(cols.view(np.int64)).cuda()
-    got = sharded.msm_phase_device(bases, d.data_ptr(), n, m, 0, mode=mode)
+    # the stream contract: everything is ordered on torch's current stream -- here a non-default one for the sharded
+    # call (looked up when no handle is given) and the default stream for the unsplit one; a foreign handle is refused
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = sharded.msm_phase_device(bases, d.data_ptr(), n, m, mode=mode)
+        try:
+            sharded.msm_phase_device(bases, d.data_ptr(), n, m, 0, mode=mode)
+            raise AssertionError("a stream other than the current one was accepted")
+        except ValueError:
+            pass
+    torch.cuda.current_stream().wait_stream(side)
     whole = sharded.msm_phase_device(bases, d.data_ptr(), n, m, 0, mode="single")
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, "got%d.npy" % rank), got.cpu().numpy().view(np.uint64))
@@ -158,6 +169,55 @@ def test_one_process_two_contexts_shard_the_host_pointer_entry_points():
     """h2_init_devices in a fresh process (the context list is per process and the other tests use h2_init(0))"""
     r = subprocess.run([sys.executable, "-c", _TWO_CONTEXTS % ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "two contexts ok" in r.stdout, r.stdout + r.stderr
+
+
+_SHARDED_PROVER = r'''
+import ctypes, hashlib, os, sys
+ROOT = %r
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import halo2_prover_amd as h2
+from halo2_prover_amd import api
+import test_capi_product as T
+api.init_devices([0, 0])                      # two contexts on the one GPU
+L = h2.load()
+assert L.h2_device_count() == 2
+L.h2_selftest_set_shard_min_rows(8)           # spread even the k = 4 proof's commitments (16 rows) over the contexts
+golden = {4: T.golden("params_k4.bin"), 6: T.golden("params_k6.bin")}
+done = 0
+for name, k, js, idx in (("arithmetic", 4, T.ARITH_INPUT, 1), ("poseidon", 6, T.POSEIDON_INPUT, 2),
+                         ("collatz", 10, T.COLLATZ_INPUT, 0), ("poseidon", 11, T.POSEIDON_INPUT, 2),
+                         ("poseidon", 16, T.POSEIDON_INPUT, 2)):
+    rng = T.Stream(0)
+    params = T.c_setup(L, k, rng)
+    assert hashlib.sha256(params).hexdigest() == T.PARAMS_SHA256[k], k
+    if k in golden:
+        assert params == golden[k]
+    before = L.h2_selftest_sharded_commits()
+    proof = T.c_prove(L, params, js, idx, rng)
+    assert L.h2_selftest_sharded_commits() > before, "the commit phases were not spread over the two contexts"
+    assert hashlib.sha256(proof).hexdigest() == T.PROOF_SHA256[(name, k)], (name, k)
+    assert T.c_verify(L, params, proof, js, idx) == (0, 1)
+    # the default threshold: small proofs stay on one context, k >= 11 is spread; the bytes do not change
+    L.h2_selftest_set_shard_min_rows(0)
+    before = L.h2_selftest_sharded_commits()
+    rng = T.Stream(0)
+    T.c_setup(L, k, rng)
+    assert hashlib.sha256(T.c_prove(L, params, js, idx, rng)).hexdigest() == T.PROOF_SHA256[(name, k)]
+    assert (L.h2_selftest_sharded_commits() > before) == (k >= 11), k
+    L.h2_selftest_set_shard_min_rows(8)
+    done += 1
+print("sharded prover ok", done)
+'''
+
+
+def test_cpp_prover_spreads_its_commit_phases_over_two_contexts_and_keeps_the_bytes():
+    """h2_generate_proof with two contexts (h2_init_devices, both on the one GPU here): every commit phase of keygen and
+    create_proof is split by point range, the partial sums are added on the prover's device, and all five recorded proofs
+    come out byte for byte (GWC and SHPLONK); reference surface: /root/reference/circuits/src/utils.rs:72-123, one
+    create_proof call"""
+    r = subprocess.run([sys.executable, "-c", _SHARDED_PROVER % ROOT], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sharded prover ok 5" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_two_streams_at_once_give_the_one_stream_results(h2):

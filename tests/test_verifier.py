@@ -112,6 +112,10 @@ def test_accepts_the_recorded_arithmetic_proof_and_rejects_corruptions(h2):
         bad = bytearray(proof)
         bad[pos] ^= 0x04
         assert V.wasm_verify_proof(params, bytes(bad), ARITH_INPUT, 1) is False, pos
+    # a point at infinity where a commitment / an opening point belongs: the reference's read_point refuses it
+    for at in (0, 64, len(proof) - 32):
+        for enc in (bytes(31) + b"\x80", bytes(32)):
+            assert V.wasm_verify_proof(params, proof[:at] + enc + proof[at + 32:], ARITH_INPUT, 1) is False, at
 
 
 @pytest.mark.gpu
