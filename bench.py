@@ -896,11 +896,14 @@ def proof_generation(k):
     ok2 = ctypes.c_int(0)
     h2lib.check(L.h2_verify_proof(params, len(params), out.raw[:ln.value], ln.value, js, 2, ctypes.byref(ok2)), "h2_verify_proof")
     os_rng["os_rng_proof_verified"] = bool(ok2.value)
-    # the Python mirror on the same stream (keygen + create_proof, params already parsed)
+    # the Python mirror on the same stream (keygen + create_proof, params already parsed).  Not inside a multi-rank
+    # group: the mirror shards its commit phases over the RANKS (collectives), and only rank 0 is here
+    import torch.distributed as dist
+    alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
     rng.counter = after_setup
-    pparams = prover.ParamsKZG.read(params)
+    pparams = prover.ParamsKZG.read(params) if alone else None
     mirror = []
-    for _ in range(2):
+    for _ in range(2 if alone else 0):
         rng.counter = after_setup
         ta = time.perf_counter()
         circuit = prover.PoseidonCircuit([1, 2])
@@ -917,7 +920,8 @@ def proof_generation(k):
             "with_params_read_ms": round(runs[3][0] * 1e3, 2),
             "proof_gen_first_call_ms": round(runs[0][0] * 1e3, 1),
             "verify_ms": round(verify_ms, 1), "verified": bool(ok.value), **os_rng,
-            "python_mirror_proof_gen_ms": round(mirror[1][0] * 1e3, 1), "python_mirror_same_bytes": mirror[1][1] == digest,
+            "python_mirror_proof_gen_ms": round(mirror[1][0] * 1e3, 1) if mirror else None,
+            "python_mirror_same_bytes": (mirror[1][1] == digest) if mirror else None,
             "proof_bytes": nbytes, "proof_sha256": digest, "bit_identical_to_reference": same,
             "note": "proof_gen_ms = one h2_generate_proof call with the key rebuilt as wasm_generate_proof does: JSON, keygen "
                     "on the empty circuit, witness, create_proof; wall clock, SRS tables resident from an earlier call "

@@ -232,12 +232,13 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
   const char* table = (const char*)be.table[ctx_index(&c)] + first_base * 64;
   for (size_t j0 = 0; j0 < m; j0 += group) {
     const size_t mm = m - j0 < group ? m - j0 : group;
-    MsmWorkspace ws = msm_workspace(n, mm, be.geom, g_msm_guard ? 256u : 0u, be.n - first_base, g_sort2_pack);
+    MsmWorkspace ws = msm_workspace(n, mm, be.geom, g_msm_guard ? 256u : 0u, be.n, g_sort2_pack);
     if (ws.E >= (1ull << 31) || ws.K >= (1ull << 31)) return H2_EINVAL;
     int rc = arena_acquire(c.msm_ws, ws.total, stream);
     if (rc != H2_OK) return rc;
-    // every kernel's index range against the region it indexes, before anything is enqueued
-    if (const char* broken = msm_check(ws, be.geom, n, mm, col_stride, (uint32_t)(be.n - first_base), c.msm_ws.bytes)) {
+    // every kernel's index range against the region it indexes, before anything is enqueued.  (n_bases is the
+    // REGISTERED length whatever the range: a sorted entry is w * be.n + i relative to the table row of first_base)
+    if (const char* broken = msm_check(ws, be.geom, n, mm, col_stride, (uint32_t)be.n, c.msm_ws.bytes)) {
       g_h2.last_error = std::string("msm launch geometry: ") + broken;
       return H2_EDEVICE;
     }

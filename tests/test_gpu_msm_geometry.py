@@ -80,6 +80,32 @@ def test_awkward_shapes_stay_inside_their_regions(h2, guarded, curve, n_bases, n
         bases.release()
 
 
+@pytest.mark.parametrize("n_bases,first,n", [(1 << 18, 1 << 17, 1 << 17), (1 << 18, 12345, 200000), (1 << 16, 30000, 35536)])
+def test_point_ranges_of_the_bases(h2, guarded, n_bases, first, n):
+    """h2_msm_device_range: bases [first, first + n) -- one rank's share of a range-split MSM.  The sorted entries are
+    w * n_bases + i with the REGISTERED length (a two-level sort that sized its packed entries for the range's length
+    let the key bits overlap them: found by the 2-rank bench at 2^20)"""
+    import torch
+    lib = guarded
+    curve = "bn254"
+    b = bases_of(curve, n_bases)
+    bases = h2.Bases(curve, b)
+    try:
+        cols = np.stack([scalars(curve, n_bases, 70 + j) for j in range(2)])
+        d = torch.from_numpy(cols.view(np.int64)).cuda()
+        out = torch.zeros((2, 12), dtype=torch.int64, device="cuda")
+        bases.msm_device_range(d.data_ptr() + first * 32, first, n, n_bases, 2, out.data_ptr())
+        torch.cuda.synchronize()
+        launches, violations, msg = guard_report(lib)
+        assert launches >= 1 and violations == 0, msg
+        res = out.cpu().numpy().view(np.uint64)
+        for j in range(2):
+            want = O.to_affine(CID[curve], O.best_multiexp(CID[curve], cols[j][first:first + n].copy(), b[first:first + n].copy(), threads=8))
+            assert np.array_equal(O.to_affine(CID[curve], res[j]), want), j
+    finally:
+        bases.release()
+
+
 def test_two_level_sort_with_the_side_array(h2, guarded):
     """at 2^24 bases an entry (w * n + i | sign) has no spare bits for the key's low bits, which then travel in a byte
     array; guard(3) selects that layout at 2^18"""

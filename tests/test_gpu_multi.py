@@ -80,6 +80,7 @@ def _phase_worker(rank, world, port, curve, n, m, mode, out_dir):
 
 
 @pytest.mark.parametrize("curve,n,m,mode", [("bn254", 1 << 14, 1, "range"), ("pallas", 1 << 14, 3, "range"),
+                                            ("bn254", 1 << 18, 1, "range"),      # the two-level sort on a point range
                                             ("bn254", 5000, 4, "columns"), ("bn254", 5000, 5, None)])
 def test_phase_split_over_two_ranks_equals_the_unsplit_result(tmp_path, curve, n, m, mode):
     world = 2
