@@ -38,7 +38,17 @@
  * h2_msm_batch / h2_ntt_batch shard their columns column j -> device j mod n, h2_msm splits one long MSM by
  * contiguous point range and adds the n partial sums; results travel as 64/96-byte points through host memory, so
  * no device-to-device collective is needed inside one process.  *_device entry points act on the context of the
- * calling thread's current HIP device.
+ * calling thread's current HIP device.  The product surface uses the contexts too: h2_generate_proof (keygen and
+ * create_proof) spreads every commit phase over them by point range -- context g commits rows [n g / G, n (g+1) / G)
+ * of every column of the phase against its replica of the table; the other contexts' shares of the columns and the
+ * G x m partial sums travel device to device (peer copies) and the sums are added on the prover's device -- and
+ * produces the same proof bytes as with one context (tests/test_gpu_multi.py).
+ *
+ * Trust.  h2_generate_proof / h2_verify_proof keep the SRS tables and keys of the last few params blobs and recognise a
+ * blob by a fast fingerprint (eight multiply-xorshift lanes over every byte, finished through Blake2b with the header
+ * and the G2 tail): it guards against accidents, NOT against a party who crafts a second blob to collide with a cached
+ * one.  Params must come from a source the caller trusts (as the reference's own flow assumes: the UI generates them);
+ * a verifier that takes params from an untrusted party calls h2_params_cache_clear() before h2_verify_proof.
  */
 #ifndef H2HIP_H
 #define H2HIP_H
