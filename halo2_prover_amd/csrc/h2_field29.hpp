@@ -216,9 +216,40 @@ H2_HD void columns2(int64_t& acc, const int32_t* a, const int32_t* b, const int3
 }
 }  // namespace detail29
 
+// The limb products are signed 32 x 32 -> 64 multiply-adds: ONE v_mad_i64_i32 each.  But where the optimiser can PROVE a
+// limb non-negative (a value just unpacked or masked) it rewrites that operand's sign extension as a zero extension,
+// and the back end then has neither its signed nor its unsigned pattern for sext(a) * zext(b): it multiplies 32 x 64
+// bits -- two v_mad_u64_u32, two moves, and for the signed top limbs two v_mul_lo_u32 and a v_add3_u32 more (seen in
+// msm_chunk_kernel's ISA: 1211 multiply-adds + 112 v_mul_lo_u32 per point addition against 1062 limb products).  An
+// empty asm statement per operand limb hides the range from the optimiser and costs no instruction.
+H2_HD int32_t fe29_opaque(int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(x));
+#endif
+  return x;
+}
+template <class FP>
+H2_HD void fe29_opaque_limbs(int32_t* o, const Fe29<FP>& a) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) o[i] = fe29_opaque(a.v[i]);
+}
+
 // a b / R' (see the invariants at the top)
 template <class FP>
 H2_HD Fe29<FP> fe29_mul(const Fe29<FP>& a, const Fe29<FP>& b) {
+  int64_t acc = 0;
+  int32_t m[9], av[9], bv[9];
+  fe29_opaque_limbs(av, a);
+  fe29_opaque_limbs(bv, b);
+  Fe29<FP> r;
+  detail29::columns<FP, 0>(acc, av, bv, m, r.v);
+  r.v[8] = (int32_t)acc;
+  return r;
+}
+// the same product with the limbs' ranges left visible to the optimiser (the ceiling microbenchmark times both forms
+// and reports the faster: on two operands it knows to be non-negative the compiler picks v_mad_u64_u32 throughout)
+template <class FP>
+H2_HD Fe29<FP> fe29_mul_plain(const Fe29<FP>& a, const Fe29<FP>& b) {
   int64_t acc = 0;
   int32_t m[9];
   Fe29<FP> r;
@@ -232,11 +263,12 @@ H2_HD Fe29<FP> fe29_mul(const Fe29<FP>& a, const Fe29<FP>& b) {
 template <class FP>
 H2_HD Fe29<FP> fe29_sqr(const Fe29<FP>& a) {
   int64_t acc = 0;
-  int32_t m[9], a2[9];
+  int32_t m[9], av[9], a2[9];
+  fe29_opaque_limbs(av, a);
 #pragma unroll
-  for (int i = 0; i < 9; i++) a2[i] = a.v[i] * 2;
+  for (int i = 0; i < 9; i++) a2[i] = fe29_opaque(av[i] * 2);
   Fe29<FP> r;
-  detail29::columns_sq<FP, 0>(acc, a.v, a2, m, r.v);
+  detail29::columns_sq<FP, 0>(acc, av, a2, m, r.v);
   r.v[8] = (int32_t)acc;
   return r;
 }
@@ -246,11 +278,14 @@ H2_HD Fe29<FP> fe29_sqr(const Fe29<FP>& a) {
 template <class FP>
 H2_HD Fe29<FP> fe29_mul_sub(const Fe29<FP>& a, const Fe29<FP>& b, const Fe29<FP>& c, const Fe29<FP>& d) {
   int64_t acc = 0;
-  int32_t m[9], nc[9];
+  int32_t m[9], av[9], bv[9], nc[9], dv[9];
+  fe29_opaque_limbs(av, a);
+  fe29_opaque_limbs(bv, b);
+  fe29_opaque_limbs(dv, d);
 #pragma unroll
-  for (int i = 0; i < 9; i++) nc[i] = -c.v[i];
+  for (int i = 0; i < 9; i++) nc[i] = fe29_opaque(-c.v[i]);
   Fe29<FP> r;
-  detail29::columns2<FP, 0>(acc, a.v, b.v, nc, d.v, m, r.v);
+  detail29::columns2<FP, 0>(acc, av, bv, nc, dv, m, r.v);
   r.v[8] = (int32_t)acc;
   return r;
 }

@@ -28,6 +28,7 @@
 #pragma once
 #include "h2_field29.hpp"
 #include "h2_ntt.hpp"
+#include <algorithm>
 
 namespace h2 {
 
@@ -376,7 +377,8 @@ inline hipError_t ntt29_launch(U128* data, U128* scratch, const void* tables, ui
     P.has_scale = (scale && P.is_final && !in_table) ? 1u : 0u;
     P.tw_global = ntt29_tw_global(P) ? 1u : 0u;
     const uint32_t* radix = (const uint32_t*)((const char*)tables + tb.off_radix[p]);
-    hipLaunchKernelGGL(ntt29_pass_kernel<FP>, grid, dim3(pl.threads[p]), ntt29_lds_bytes(P), stream, src, dst, tw, radix,
+    static const size_t lds_pad = (size_t)tune_int("H2_TUNE_NTT_LDS_PAD", 0);      // tuning builds: fewer blocks per CU
+    hipLaunchKernelGGL(ntt29_pass_kernel<FP>, grid, dim3(pl.threads[p]), std::min<size_t>(ntt29_lds_bytes(P) + lds_pad, 160 * 1024), stream, src, dst, tw, radix,
                        canon, P, n, sc);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
