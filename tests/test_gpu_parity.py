@@ -86,6 +86,36 @@ def test_ntt_inverse_round_trip_and_batch(h2):
         assert np.array_equal(c, want)
 
 
+@pytest.mark.parametrize("curve", ["bn254", "pallas"])
+def test_scaled_ntt_all_plan_shapes(h2, curve):
+    """h2_ntt_scaled_device (EvaluationDomain::ifft's 1/n and other constants): one pass multiplies in its final pass,
+    two passes take the constant from inter-pass twiddles built with it (a table per (omega, log n, constant)), three
+    passes multiply in the final pass again.  Two constants against the same omega must not share a table; the
+    unscaled transform of the same omega in between must stay unscaled."""
+    import ctypes
+    import torch
+    f = scalar_field(curve)
+    fid = O.CURVE_SCALAR_FIELD[CID[curve]]
+    L = h2.load()
+    for log_n in (3, 9, 10, 11, 13, 16, 20, 21):
+        n = 1 << log_n
+        a = rand_scalars(curve, n, seed=0x30 + log_n)
+        w = omega_limbs(curve, log_n, inverse=True)
+        plain = O.best_fft(fid, a, w, log_n, threads=8).reshape(n, 4)
+        for c in (pow(n, -1, f.p), 0x123456789ABCDEF0FEDCBA9876543210 % f.p, 1):
+            cm = np.array(f.limbs(c), dtype=np.uint64)
+            d = torch.from_numpy(a.view(np.int64)).cuda()
+            st = L.h2_ntt_scaled_device(CID[curve], ctypes.c_void_p(d.data_ptr()), 1, w.ctypes.data, log_n, cm.ctypes.data, None)
+            assert st == 0
+            torch.cuda.synchronize()
+            want = O.field_mul_many(fid, plain.reshape(-1), np.tile(cm, n)).reshape(n, 4)
+            assert np.array_equal(d.cpu().numpy().view(np.uint64), want), (log_n, hex(c))
+            d2 = torch.from_numpy(a.view(np.int64)).cuda()
+            h2.ntt_device(d2.data_ptr(), 1, w, log_n, curve)
+            torch.cuda.synchronize()
+            assert np.array_equal(d2.cpu().numpy().view(np.uint64), plain), log_n
+
+
 def test_ntt_rejects_bad_length(h2):
     a = rand_scalars("bn254", 8)
     with pytest.raises(ValueError):
