@@ -196,6 +196,21 @@ def best_fft(a, omega, log_n, curve="bn254"):
     return a
 
 
+def best_fft_group(points_jac, omega, log_n, curve="bn254"):
+    """best_fft over group elements (G = C::Curve, the FftGroup impl g_to_lagrange uses): in-place transform of a
+    (n, 12) uint64 array of Jacobian points; natural order in and out, unscaled."""
+    _ensure_init()
+    a = points_jac
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("best_fft_group: points must be a C-contiguous numpy uint64 array (transformed in place)")
+    if a.size != 12 << log_n:
+        raise ValueError("best_fft_group: a.len() != 1 << log_n (%d vs %d)" % (a.size // 12, 1 << log_n))
+    omega = np.ascontiguousarray(omega, dtype=np.uint64).reshape(4)
+    st = _lib.load().h2_fft_group(_curve_id(curve), a.ctypes.data, omega.ctypes.data, log_n)
+    _lib.check(st, "h2_fft_group")
+    return a
+
+
 def best_fft_batch(columns, omega, log_n, curve="bn254"):
     """The same transform over m independent columns in one launch sequence."""
     _ensure_init()

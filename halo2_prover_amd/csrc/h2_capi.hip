@@ -913,6 +913,39 @@ int h2_ntt_batch(h2_curve_t curve, uint64_t* const* cols, size_t m, const uint64
   return H2_OK;
 }
 
+// best_fft over group elements (FftGroup for C::Curve): n = 2^log_n Jacobian points in place, natural order, unscaled
+int h2_fft_group_device(h2_curve_t curve, void* d_points_jac, const uint64_t omega[4], uint32_t log_n, void* stream_) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  Call k(stream_);
+  if (k.rc != H2_OK) return k.rc;
+  if (!curve_ok((int)curve) || !d_points_jac || !omega || log_n > 26) return H2_EINVAL;
+  if (log_n == 0) return H2_OK;
+  const CurveOps* ops = ops_of((int)curve);
+  int rc = arena_acquire(k.c->msm_ws, ops->group_fft_scratch(log_n), k.stream);      // the MSM workspace, idle here
+  if (rc != H2_OK) return rc;
+  hipError_t e = ops->group_fft(d_points_jac, d_points_jac, k.c->msm_ws.p, omega, log_n, k.stream);
+  if (e != hipSuccess) return dev_fail(e, "group fft kernels");
+  return arena_release(k.c->msm_ws, k.stream);
+}
+
+int h2_fft_group(h2_curve_t curve, uint64_t* points_jac, const uint64_t omega[4], uint32_t log_n) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  if (!g_h2.ready) return H2_ENOTINIT;
+  if (!curve_ok((int)curve) || !points_jac || !omega || log_n > 26) return H2_EINVAL;
+  if (log_n == 0) return H2_OK;
+  DevCtx& c = g_h2.ctx[0];
+  DeviceGuard dg(c.device);
+  const size_t bytes = ((size_t)96) << log_n;
+  int rc = arena_acquire(c.stage, bytes, c.stream);
+  if (rc != H2_OK) return rc;
+  H2_TRY(hipMemcpyAsync(c.stage.p, points_jac, bytes, hipMemcpyHostToDevice, c.stream));
+  rc = h2_fft_group_device(curve, c.stage.p, omega, log_n, c.stream);
+  if (rc != H2_OK) return rc;
+  H2_TRY(hipMemcpyAsync(points_jac, c.stage.p, bytes, hipMemcpyDeviceToHost, c.stream));
+  H2_TRY(hipStreamSynchronize(c.stream));
+  return arena_release(c.stage, c.stream);
+}
+
 int h2_ntt(h2_curve_t curve, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
   uint64_t* cols[1] = {a};
   return h2_ntt_batch(curve, cols, 1, omega, log_n);

@@ -5,6 +5,7 @@
 #include "h2_ntt29.hpp"
 #include "h2_tune.hpp"
 #include "h2_poly.hpp"
+#include "h2_group_fft.hpp"
 
 #include <cstring>
 
@@ -95,6 +96,12 @@ hipError_t ntt_launch_(void* d_data, void* d_scratch, const void* d_tw, uint32_t
   Fe<FS> sc;
   if (scale) memcpy(sc.v, scale, 32);
   return ntt29_launch<FS>((U128*)d_data, (U128*)d_scratch, d_tw, log_n, m, s, scale ? &sc : nullptr);
+}
+size_t group_fft_scratch(uint32_t log_n) { return gfft_scratch_bytes(log_n); }
+hipError_t group_fft(const void* d_in_jac, void* d_out_jac, void* d_scratch, const uint64_t omega[4], uint32_t log_n, hipStream_t s) {
+  Fe<FS> w;
+  memcpy(w.v, omega, 32);
+  return gfft_launch<CV>((const U128*)d_in_jac, (U128*)d_out_jac, d_scratch, w, log_n, s);
 }
 hipError_t poly_scale(void* d_a, size_t total, const uint64_t c[4], hipStream_t s) {
   Fe<FS> cv;
@@ -346,7 +353,7 @@ int selftest_digits(const uint64_t* scalar_mont, size_t n_for_geometry, uint32_t
 }
 
 const CurveOps OPS = {CV::ID,      FS::ID,      FS::NUM_BITS, kernel_setup, table_build, msm_launch_,    srs_powers, fixed_base_mul, msm_small,
-                      to_affine,   points_sum, ntt_table_bytes, ntt_scale_in_table, ntt_twiddles, ntt_launch_, poly_scale, poly_powers, poly_mul_periodic,
+                      to_affine,   points_sum, ntt_table_bytes, ntt_scale_in_table, ntt_twiddles, ntt_launch_, group_fft_scratch, group_fft, poly_scale, poly_powers, poly_mul_periodic,
                       poly_pointwise, poly_inverse, poly_divide_linear, poly_prefix_product, chacha20_scalars, selftest_field, selftest_curve,
                       selftest_field_device, selftest_curve_device, selftest_digits, modmul_rate};
 

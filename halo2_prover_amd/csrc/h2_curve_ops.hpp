@@ -45,6 +45,11 @@ struct CurveOps {
   hipError_t (*ntt_twiddles)(void* d_tables, const uint64_t omega[4], uint32_t log_n, hipStream_t s, const uint64_t* scale /* or null */);
   hipError_t (*ntt_launch)(void* d_data, void* d_scratch, const void* d_tw, uint32_t log_n, size_t m,
                            hipStream_t s, const uint64_t* scale /* 4 limbs or null */);
+  // best_fft over group elements (FftGroup for the curve: g_to_lagrange): n = 2^log_n Jacobian points (API form) in,
+  // the transform out (may alias), natural order, unscaled; d_scratch: group_fft_scratch(log_n) bytes
+  size_t (*group_fft_scratch)(uint32_t log_n);
+  hipError_t (*group_fft)(const void* d_in_jac, void* d_out_jac, void* d_scratch, const uint64_t omega[4], uint32_t log_n,
+                          hipStream_t s);
   // pointwise polynomial kernels over the scalar field (EvaluationDomain pieces)
   hipError_t (*poly_scale)(void* d_a, size_t total, const uint64_t c[4], hipStream_t s);
   hipError_t (*poly_powers)(void* d_a, size_t n, size_t m, const uint64_t g[4], hipStream_t s);

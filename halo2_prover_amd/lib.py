@@ -50,6 +50,8 @@ SYMBOLS = {
     "h2_ntt": (_I, [_I, _P, _P, _U32]),
     "h2_ntt_batch": (_I, [_I, _P, _Z, _P, _U32]),
     "h2_ntt_device": (_I, [_I, _P, _Z, _P, _U32, _P]),
+    "h2_fft_group": (_I, [_I, _P, _P, _U32]),
+    "h2_fft_group_device": (_I, [_I, _P, _P, _U32, _P]),
     "h2_ntt_scaled_device": (_I, [_I, _P, _Z, _P, _U32, _P, _P]),
     "h2_poly_scale_device": (_I, [_I, _P, _Z, _Z, _P, _P]),
     "h2_poly_coset_device": (_I, [_I, _P, _Z, _Z, _P, _P]),

@@ -194,6 +194,16 @@ typedef struct {
 int h2_msm_plan(uint64_t bases_handle, h2_msm_plan_t* out);
 
 
+/* ---- best_fft over group elements ------------------------------------------------------------
+ * Replaces halo2_proofs::arithmetic::best_fft<Scalar, G> for G = C::Curve (the FftGroup impl of the curve's projective
+ * points): the reference's only use is ParamsKZG::new -> g_to_lagrange, reached from
+ * /root/reference/circuits/src/utils.rs:59-61 (g_lagrange = n^-1 * best_fft(g, omega^-1, k)).  n = 2^log_n Jacobian
+ * points (96 bytes, Montgomery limbs, identity z = 0) transformed IN PLACE, natural order in and out, unscaled, omega in
+ * the scalar field's Montgomery form.  Results are group elements: compare after affine normalisation.
+ * h2_fft_group: host pointer, synchronous; h2_fft_group_device: device pointer, asynchronous on `stream`. */
+int h2_fft_group(h2_curve_t curve, uint64_t* points_jac, const uint64_t omega[4], uint32_t log_n);
+int h2_fft_group_device(h2_curve_t curve, void* d_points_jac, const uint64_t omega[4], uint32_t log_n, void* stream);
+
 /* ---- SRS generation == the g vector of ParamsKZG::new(k) -----------------------------------
  * d_out_affine[i] = [s^i] G for i < n (device memory, n*64 bytes), s in Montgomery form.
  * Counterpart of the setup loop reached from /root/reference/circuits/src/utils.rs:59-61 and

@@ -116,6 +116,63 @@ def test_scaled_ntt_all_plan_shapes(h2, curve):
             assert np.array_equal(d2.cpu().numpy().view(np.uint64), plain), log_n
 
 
+# ---------------------------------------------------------------------- group-element FFT ----
+def _affine_to_jac(curve, aff):
+    """(n, 8) affine points -> (n, 12) Jacobian with z = 1 (Montgomery), identity (0, 0) -> z = 0"""
+    f = R.CURVES[curve].base
+    n = aff.shape[0]
+    jac = np.zeros((n, 12), dtype=np.uint64)
+    jac[:, :8] = aff
+    one = np.array(f.limbs(1), dtype=np.uint64)
+    for i in range(n):
+        if aff[i].any():
+            jac[i, 8:] = one
+    return jac
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8])
+def test_group_fft_matches_oracle(h2, curve, log_n):
+    """h2_fft_group == best_fft over C::Curve (the FftGroup impl behind g_to_lagrange), against the oracle's restatement;
+    inputs include the identity, a repeated point and a point next to its negative (exceptional additions)"""
+    n = 1 << log_n
+    c = R.CURVES[curve]
+    aff = rand_bases(curve, n, seed=0xC0 + log_n)
+    if n >= 8:
+        aff[2] = 0
+        aff[5] = aff[4]
+        neg = aff[6].copy()
+        y = c.base.from_mont(O.limbs_to_int(neg[4:]))
+        neg[4:] = np.array(c.base.limbs((-y) % c.base.p), dtype=np.uint64)
+        aff[7] = neg
+    jac = _affine_to_jac(curve, aff)
+    w = omega_limbs(curve, log_n, inverse=True)
+    want = O.to_affine(CID[curve], O.group_fft(CID[curve], jac.reshape(-1), w, log_n)).reshape(n, 8)
+    got = jac.copy()
+    h2.best_fft_group(got, w, log_n, curve)
+    assert np.array_equal(O.to_affine(CID[curve], got.reshape(-1)).reshape(n, 8), want)
+
+
+@pytest.mark.parametrize("k", [4, 6])
+def test_group_fft_reproduces_g_lagrange_of_the_recorded_params(h2, k):
+    """ParamsKZG::new's g_to_lagrange on the reference's own params files (sha256-pinned): g_lagrange = n^-1 *
+    best_fft(g, omega^-1, k).  The transform's output is compared with [n] g_lagrange, every point."""
+    import os
+    f = R.BN_FR
+    n = 1 << k
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "params_k%d.bin" % k), "rb").read()
+    g = np.frombuffer(data, dtype=np.uint64, count=8 * n, offset=4).reshape(n, 8).copy()
+    gl = np.frombuffer(data, dtype=np.uint64, count=8 * n, offset=4 + 64 * n).reshape(n, 8).copy()
+    jac = _affine_to_jac("bn254", g)
+    h2.best_fft_group(jac, omega_limbs("bn254", k, inverse=True), k, "bn254")
+    got = O.to_affine(0, jac.reshape(-1)).reshape(n, 8)
+    n_m = np.array(f.limbs(n), dtype=np.uint64)
+    for i in range(n):
+        assert np.array_equal(got[i], O.to_affine(0, O.scalar_mul(0, n_m, gl[i]))), i
+    with pytest.raises(ValueError):
+        h2.best_fft_group(jac, omega_limbs("bn254", k), k + 1, "bn254")
+
+
 def test_ntt_rejects_bad_length(h2):
     a = rand_scalars("bn254", 8)
     with pytest.raises(ValueError):
