@@ -260,9 +260,10 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
     void* dst = (char*)d_out + j0 * out_sz;
     hipError_t e = ops->msm_launch(table, per_column ? col_tables : nullptr, (uint32_t)be.n,
                                    (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
-                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1, c.tail_wanted ? c.tail_event : nullptr,
+                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1, (c.tail_wanted && !ev1) ? c.tail_event : nullptr,
                                    affine_out ? nullptr : dst);
     c.tail_recorded = c.tail_wanted;
+    c.tail_wait = ev1 ? ev1 : c.tail_event;
     if (e != hipSuccess) return dev_fail(e, "msm_launch");
     if (g_msm_guard) {
       uint32_t* d_bad = nullptr;
@@ -586,7 +587,7 @@ int h2_stream_wait_msm_tail(void* stream_) {
   std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
   Call k(stream_);
   if (k.rc != H2_OK) return k.rc;
-  if (k.c->tail_recorded) H2_TRY(hipStreamWaitEvent(k.stream, k.c->tail_event, 0));
+  if (k.c->tail_recorded && k.c->tail_wait) H2_TRY(hipStreamWaitEvent(k.stream, k.c->tail_wait, 0));
   k.c->tail_wanted = true;          // from now on every MSM of this context marks the end of its accumulate kernel
   return H2_OK;
 }

@@ -44,6 +44,9 @@ struct DevCtx {
   Arena msm_ws, ntt_ws, stage, div_ws;
   hipEvent_t shard_ev = nullptr;     // C++ prover: this context's share of a commit phase is done / the columns are final
   hipEvent_t tail_event = nullptr;   // recorded behind the accumulate kernel of the latest MSM (h2_stream_wait_msm_tail)
+  hipEvent_t tail_wait = nullptr;    // the event to wait on for that: tail_event, or the profiling stop event of the
+                                     // launch when profiling records one at the same place (an event record costs ~6 us
+                                     // of stream time: profiles/r03 step timeline)
   bool tail_recorded = false, tail_wanted = false;   // the event costs ~5 us per MSM: recorded once somebody asked
   std::vector<TwiddleEntry> twiddles;
   uint64_t stamp = 0;

@@ -262,7 +262,7 @@ struct Dev {
   }
   // `on` waits for the accumulate kernel of the MSM enqueued last on this context (commit_begin)
   void wait_msm_tail(hipStream_t on) {
-    if (c->tail_recorded && c->tail_event) hip_ok(hipStreamWaitEvent(on, c->tail_event, 0), "hipStreamWaitEvent(tail)");
+    if (c->tail_recorded && c->tail_wait) hip_ok(hipStreamWaitEvent(on, c->tail_wait, 0), "hipStreamWaitEvent(tail)");
   }
   // the second stream of this context (non-blocking) and three events to hand work back and forth
   hipStream_t side() {
