@@ -75,8 +75,10 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   // measured on the Poseidon proof shape (bench.py --k 12 / 14 / 16 / 18) and on single 2^20 columns: wider windows
   // save additions in the accumulate kernel (W = ceil(256 / c)) but every bucket costs ~16 point operations in the
-  // tail, so the best width is log2 n - 3 up to 2^16 and log2 n - 4 above
-  int c = (int)lg - (lg <= 16 ? 3 : 4);
+  // tail, so the best width is log2 n - 3 up to 2^15 and log2 n - 4 from 2^16 (round 3: with the accumulate kernel 17 %
+  // faster the fixed costs weigh more -- at 2^16 c = 11 / 12 / 13 / 14 give 2.93 / 2.69 / 2.73 / 2.85 ms per step,
+  // tools/sweep_c.sh)
+  int c = (int)lg - (lg <= 15 ? 3 : 4);
   c = tune_int("H2_TUNE_C", c);             // tuning builds only (h2_tune.hpp)
   if (c < 6) c = 6;
   if (c > (int)MSM_MAX_C) c = (int)MSM_MAX_C;

@@ -59,7 +59,7 @@ def test_every_shape_passes_the_bounds_proof(lib, curve):
 
 def test_the_three_sorts_are_chosen_where_designed(lib):
     _, a = check(lib, 1, 1 << 16, 1 << 16, 4)
-    assert (a["c"], a["B"], a["staged"], a["sort2"]) == (13, 4096, 1, 0)
+    assert (a["c"], a["B"], a["staged"], a["sort2"]) == (12, 2048, 1, 0)
     _, b = check(lib, 1, 1 << 20, 1 << 20, 1)
     assert (b["c"], b["W"], b["B"], b["sort2"]) == (16, 16, 32768, 1)
     _, c = check(lib, 1, 3000, 3000, 2)
