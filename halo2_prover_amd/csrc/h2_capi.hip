@@ -208,7 +208,13 @@ static std::string g_guard_first;
 static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
   const uint64_t per_col = (uint64_t)be.geom.W * n;
   const uint64_t by_entries = g_msm_max_entries / per_col;
-  const uint64_t by_keys = ((1ull << 31) - 1) / be.geom.B;
+  uint64_t by_keys = ((1ull << 31) - 1) / be.geom.B;
+  // wide windows go through the two-level sort, whose one-block scan of the coarse bins holds S2_MAX_H of them: rather
+  // than fall back to the one-level sort's scattered stores, a wider batch runs in groups of that many columns
+  if (be.geom.B > 4096) {
+    const uint64_t by_bins = S2_MAX_H / msm_sort2_geom(n, be.geom).Hc;
+    if (by_bins >= 1 && by_bins < by_keys) by_keys = by_bins;
+  }
   return (size_t)(by_entries < by_keys ? by_entries : by_keys);   // 0: a single column is already too long
 }
 
