@@ -397,7 +397,7 @@ def main():
         ntt_bytes = sum(m * (1 << lg) * 64 for _, lg, m, _ in ntt_bufs.values())
         pass_bytes = sum(m * (1 << lg) * 64 * ((lg + 9) // 10) for _, lg, m, _ in ntt_bufs.values())
         ach = ntt_bytes / (phases_ms["ntt"] * 1e-3) / 1e9
-        roofline_ntt = {"bound": "hbm", "kernel": "ntt_pass_kernel (all launches of this rank's NTTs of the step)",
+        roofline_ntt = {"bound": "hbm", "kernel": "ntt29_pass_kernel (all launches of this rank's NTTs of the step)",
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                         "algorithmic_bytes_per_step": ntt_bytes, "per_pass_bytes_per_step": pass_bytes,
