@@ -35,6 +35,7 @@
 #include "h2_curve29.hpp"
 #include "h2_curve_quad.hpp"
 #include "h2_tune.hpp"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdlib>
 
@@ -1546,11 +1547,19 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
     hipLaunchKernelGGL(msm_store_tables_kernel, dim3(1), dim3(64), 0, stream, L, d_tables, (uint32_t)m);
     while ((1u << log_b) < g.B) log_b++;
   }
-  if (ev_start) (void)hipEventRecord(ev_start, stream);
-  hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
-                     (const U128* const*)d_tables, log_b, sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
-  if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-  if (ev_tail) (void)hipEventRecord(ev_tail, stream);   // from here on only small-grid kernels: other streams may fill the chip
+  // The roofline's start / stop events and the tail event (from the accumulate kernel's end on only small-grid kernels
+  // run: other streams may fill the chip) ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): as separate
+  // hipEventRecord calls each was a barrier packet of its own, ~6 us of stream time before and after the kernel
+  // (profiles/r03_step_kernel_timeline.txt).
+  hipEvent_t ev_end = ev_stop ? ev_stop : ev_tail;
+  if (ev_start || ev_end)
+    hipExtLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, ev_start, ev_end,
+                          0, table, (const U128* const*)d_tables, log_b, (const uint32_t*)sref, (const uint32_t*)chunk_first,
+                          (const uint32_t*)offsets, ws.K, ws.T, bsum, head, tail);
+  else
+    hipLaunchKernelGGL(msm_chunk_kernel<CV>, dim3((unsigned)((ws.nchunks + 255) / 256)), dim3(256), 0, stream, table,
+                       (const U128* const*)d_tables, log_b, sref, chunk_first, offsets, ws.K, ws.T, bsum, head, tail);
+  if (ev_stop && ev_tail) (void)hipEventRecord(ev_tail, stream);
   hipLaunchKernelGGL(msm_hot_reduce_kernel<CV>, dim3(1024), dim3(64), 0, stream, offsets, ws.K, ws.T, hot_slot, hot_tasks,
                      misc, ws.max_tasks, head, tail, hot_part);
   const size_t fix_threads = ws.K << ws.log_g;
