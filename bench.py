@@ -15,9 +15,11 @@ section 8(a)/App. A.4), with dense synthetic columns already resident in HBM:
 
 value = field-ops/s with the reference-parameter yardstick of SURVEY.md section 8(d):
 ops_msm(n) = S*(11n + 32(2^c-1)) + 7*256 with c = ceil(ln n), S = 256/c+1;  ops_ntt(n) = 3*(n/2)*log2 n.
-With N > 1 the SAME job is spread over the ranks (strong scaling): each MSM phase is sharded by whole columns when
-m % N == 0, else every rank takes a point range of every column; one all-gather of 96-byte points per phase over RCCL;
-NTT columns go j -> rank j mod N with no collective.
+With N > 1 every rank (one per GPU) runs the whole step on columns of its own -- per-GPU work fixed, "scaling": "weak" --
+and the commitment vector of every phase is all-gathered over RCCL (the path's one exchange step, m x 96 bytes per rank);
+value = N steps' field-ops / step time.  ONE proof's job spread over the N GPUs (each MSM phase by whole columns when
+m % N == 0, else a point range of every column per rank; NTT columns j -> rank j mod N) is the sub-record
+"one_proof_sharded", checked against the unsharded commitments.
 
 Printed keys beyond the driver contract: "roofline" (bucket-accumulate kernel, HIP-event timed
 inside the library on the launch stream), "cpu_baseline" (the CPU oracle timed on this host,
@@ -251,7 +253,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- resident inputs: the SAME job on every rank count (strong scaling) ---------------------------------------
+    # ---- resident inputs ---------------------------------------------------------------------------------------------
     seed = 0x48324D5300000000
     g_lagrange, g = make_srs(n, 0x1234567), make_srs(n, 0x7654321)
     plan = g.plan()
@@ -263,7 +265,8 @@ def main():
         [(g, args.msm_cols)] if args.workload == "msm" else []
     n_msm = sum(m for _, m in phases)
     cols_np = splitmix_columns(seed | 1, max(n_msm, 1) * n, p)
-    msm_cols = to_dev(cols_np)                # (n_msm*n, 4); every rank holds every column (32 MiB at k = 16)
+    msm_cols = to_dev(cols_np)                # (n_msm*n, 4); the same columns on every rank (32 MiB at k = 16): the
+    # one-proof sub-record needs them identical, and the values do not change what a column costs
     # NTT groups of the step, with what they depend on in a real proof (prover.py / SURVEY.md App. A.4): the
     # Lagrange -> coefficient -> extended-coset transforms of the advice + instance columns need only the witness, so
     # they run on a second stream while the commit phases' MSMs run on the first; the two permutation products' start
@@ -277,64 +280,83 @@ def main():
         ntts = [("cols", k, args.ntt_cols, False, "main")]
     else:
         ntts = []
-    ntt_bufs = {}
-    for j, (name, lg, m, inv, _) in enumerate(ntts):
-        mine = list(range(rank, m, world))     # NTT columns shard whole: column j -> rank j mod N, no collective
-        if mine:
-            allc = splitmix_columns(seed | (2 + j), m << lg, p).reshape(m, 1 << lg, 4)
-            ntt_bufs[name] = (to_dev(np.ascontiguousarray(allc[mine]).reshape(-1, 4)), lg, len(mine), omega(lg, inv))
     multi = world > 1 or (args.force_collectives and use_dist)
+
+    def build_ntt_bufs(shard):
+        bufs = {}
+        for j, (name, lg, m, inv, _) in enumerate(ntts):
+            # the one-proof job (sub-record, below) shards NTT columns whole: column j -> rank j mod N, no collective
+            mine = list(range(rank, m, world)) if shard else list(range(m))
+            if mine:
+                allc = splitmix_columns(seed | (2 + j) | (0 if shard else rank << 16), m << lg, p).reshape(m, 1 << lg, 4)
+                bufs[name] = (to_dev(np.ascontiguousarray(allc[mine]).reshape(-1, 4)), lg, len(mine), omega(lg, inv))
+        return bufs
+
+    # N > 1, the line's `value` (weak scaling: per-GPU work fixed): every rank runs the WHOLE proof-shaped step on columns
+    # of its own -- N proofs' worth of commitments and transforms on N GPUs -- and the commitment vector of every phase is
+    # all-gathered (the path's one exchange step: m x 96 bytes per rank and phase).  The north star's other reading, ONE
+    # proof's columns spread over the N GPUs (total work fixed), is the sub-record `one_proof_sharded`.
+    ntt_bufs = build_ntt_bufs(False)
+    ntt_bufs_shared = build_ntt_bufs(True) if world > 1 else ntt_bufs
     results = [None] * len(phases)
     side_stream = torch.cuda.Stream(device=dev, priority=0)
     side = side_stream.cuda_stream
     ev_start, ev_side_done = torch.cuda.Event(), torch.cuda.Event()
 
-    def run_phase(i, off, mode=None):
+    def run_phase(i, off, mode="single", gather=False):
         bases, m = phases[i]
         results[i] = sharded.msm_phase_device(bases, msm_cols.data_ptr() + off * n * 32, n, m, stream,
                                               mode=mode if multi else "single")
+        if gather and multi:
+            sharded.all_gather_rows(results[i])             # every rank holds every rank's commitments of the phase
         return off + m
 
-    def msm_phase(mode=None):
-        if mode is None and multi and world == 1:
-            mode = "range"
+    def msm_phase(mode="single"):
         off = 0
         for i in range(len(phases)):
             off = run_phase(i, off, mode)
 
-    def run_ntt(name, st):
-        if name in ntt_bufs:
-            buf, lg, m, w = ntt_bufs[name]
+    def run_ntt(name, st, bufs=None):
+        bufs = ntt_bufs if bufs is None else bufs
+        if name in bufs:
+            buf, lg, m, w = bufs[name]
             h2.ntt_device(buf.data_ptr(), m, w, lg, args.curve, st)
 
     def ntt_phase():
         for name, *_ in ntts:
             run_ntt(name, stream)
 
-    def step():
+    def step(shared=False):
+        """shared = False: this rank's own step (mode "single", commitments gathered).  shared = True: one proof's job
+        spread over the ranks (columns when m % N == 0, else point ranges; NTT columns j -> rank j mod N)."""
+        mode = (None if world > 1 else "range") if shared else "single"
+        bufs = ntt_bufs_shared if shared else ntt_bufs
         if args.workload != "poseidon":
-            msm_phase()
-            ntt_phase()
+            off = 0
+            for i in range(len(phases)):
+                off = run_phase(i, off, mode, gather=not shared)
+            for name, *_ in ntts:
+                run_ntt(name, stream, bufs)
             return
         # first stream: the five commit phases in Fiat-Shamir order.  Second stream: the transforms that wait for no
         # challenge, each group queued behind the accumulate kernel of a commit phase (h2_stream_wait_msm_tail), so
         # that it runs beside that phase's small-grid tail instead of beside its chip-filling kernel
         ev_start.record(work_stream)
         side_stream.wait_event(ev_start)
-        off = run_phase(0, 0)                   # advice
+        off = run_phase(0, 0, mode, not shared)  # advice
         L.h2_stream_wait_msm_tail(side)
-        run_ntt("advice_i", side)
-        run_ntt("advice_e_a", side)
-        off = run_phase(1, off)                 # permutation products (exist once beta, gamma do) + random polynomial
+        run_ntt("advice_i", side, bufs)
+        run_ntt("advice_e_a", side, bufs)
+        off = run_phase(1, off, mode, not shared)  # permutation products (exist once beta, gamma do) + random polynomial
         L.h2_stream_wait_msm_tail(side)
-        run_ntt("advice_e_b", side)
-        run_ntt("z_i", side)
-        run_ntt("z_e", side)
+        run_ntt("advice_e_b", side, bufs)
+        run_ntt("z_i", side, bufs)
+        run_ntt("z_e", side, bufs)
         ev_side_done.record(side_stream)
         work_stream.wait_event(ev_side_done)    # y is squeezed next; the quotient needs every extended column
-        run_ntt("h_i", stream)
-        off = run_phase(2, off)                 # quotient pieces
-        run_phase(3, off)                       # opening witnesses
+        run_ntt("h_i", stream, bufs)
+        off = run_phase(2, off, mode, not shared)  # quotient pieces
+        run_phase(3, off, mode, not shared)        # opening witnesses
 
     for _ in range(args.warmup):
         step()
@@ -359,16 +381,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # sharded == whole: every rank recomputes the phases alone on its own GPU and compares group elements
+    # one proof's job spread over the ranks (total work fixed): sharded == whole as group elements, then its time
     sharded_ok = None
+    one_proof = None
     if multi and phases:
         q = BASE_FIELD[args.curve]
+        step(shared=True)
+        torch.cuda.synchronize()
         got = [jac_to_affine_ints(r.cpu().numpy().view(np.uint64), q) for r in results]
         msm_phase(mode="single")
         torch.cuda.synchronize()
         want = [jac_to_affine_ints(r.cpu().numpy().view(np.uint64), q) for r in results]
         sharded_ok = got == want
         assert sharded_ok, "rank %d: sharded commitments differ from the unsharded ones" % rank
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            step(shared=True)
+        barrier()
+        dts = time.perf_counter() - ts
+        if use_dist:
+            t = torch.tensor([dts], dtype=torch.float64)
+            if backend == "nccl":
+                t = t.to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        one_proof = {"what": "ONE proof-shaped step spread over the %d ranks (total work fixed): each MSM phase by whole "
+                             "columns when m %% N == 0, else a point range of every column per rank; one all-gather of "
+                             "96-byte points per phase; NTT columns j -> rank j mod N" % world,
+                     "ms_per_step": round(dts / args.steps * 1e3, 4), "sharded_equals_unsharded": sharded_ok}
 
     # per-phase timing (outside the timed region; torch events see this stream because the library was
     # handed torch's current stream)
@@ -404,7 +445,7 @@ def main():
                         "ms_per_step": phases_ms["ntt"]}
 
     ops_step = n_msm * ops_msm(n) + sum(m * ops_ntt(1 << lg) for _, lg, m, _, _ in ntts)
-    value = ops_step * args.steps / dt        # the whole job's field-ops (the same job whatever N) per second
+    value = world * ops_step * args.steps / dt     # every rank ran the step on its own columns: N steps' field-ops per step time
 
     # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read
     # in-process); the committed summary is used only when it was taken on THIS build of the kernels
@@ -454,7 +495,7 @@ def main():
             roofline["modmul_frac"] = round(roofline["modmul_per_s"] / modmul["at_3_waves_per_simd"], 4)
             roofline["modmul_frac_executed"] = round(roofline["modmul_frac"] * PRODUCT_EQUIVALENTS_PER_ADD / 10.0, 4)
             if "msm" in phases_ms and n_msm:
-                whole = (n_msm * n * plan["windows"] * 10 / world) / (phases_ms["msm"] * 1e-3)
+                whole = (n_msm * n * plan["windows"] * 10) / (phases_ms["msm"] * 1e-3)     # this rank's own 16 columns
                 roofline["msm_phase_modmul_per_s"] = whole
                 roofline["msm_phase_modmul_frac"] = round(whole / modmul["at_8_waves_per_simd"], 4)
 
@@ -502,15 +543,15 @@ def main():
         if world == 1:
             par = "1 GPU"
         else:
-            par = ("one fixed job on %d ranks (%s): each MSM phase sharded by whole columns when m %% N == 0, else every "
-                   "rank takes a point range of every column; ONE all-gather of 96-byte points per phase; NTT columns "
-                   "j -> rank j mod N, no collective" % (world, "RCCL" if backend == "nccl" else
-                                                         "gloo: %d ranks share %d GPU(s)" % (world, ndev)))
+            par = ("%d ranks (%s), one per GPU: every rank runs the whole proof-shaped step on columns of its own (per-GPU "
+                   "work fixed), the commitment vector of every phase is all-gathered (m x 96 bytes per rank); the "
+                   "one-proof split is the sub-record one_proof_sharded" % (world, "RCCL" if backend == "nccl" else
+                                                                            "gloo: %d ranks share %d GPU(s)" % (world, ndev)))
         out = {
             "metric": "MSM+NTT field-ops/s", "value": value, "unit": "field-ops/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_min": per_step[0],
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit modular)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit modular)",
             "data": "synthetic (dense SplitMix64 scalars as SURVEY 8(d) defines them; bases [s^i]G made on the device instead of "
                     "8(d)'s try-and-increment points: the same cost per addition, a different distribution)",
             "parity": "bn254 pinned by the reference's recorded params / proofs; pallas and vesta self-consistent "
@@ -519,7 +560,7 @@ def main():
                        "parallelism": par, "backend": backend,
                        "msm_window_bits": plan["window_bits"], "msm_windows": plan["windows"],
                        "msm_table_bytes": plan["table_bytes"]},
-            "sharded_equals_unsharded": sharded_ok,
+            "sharded_equals_unsharded": sharded_ok, "one_proof_sharded": one_proof,
             "roofline": roofline, "roofline_ntt": roofline_ntt, "modmul_ceiling": modmul,
             "cpu_baseline": cpu, "proof_gen": proof_gen, "proof_gen_n_gpus": proof_gen_multi,
             "phases_ms": phases_ms, "overlap": overlap, "field_ops_per_step": ops_step,
