@@ -205,14 +205,15 @@ static uint64_t g_msm_max_entries = (1ull << 31) - 1;   // lowered only by h2_se
 static bool g_msm_guard = false, g_msm_guard_poke = false, g_sort2_pack = true;
 static uint64_t g_guard_launches = 0, g_guard_violations = 0;
 static std::string g_guard_first;
-static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
-  const uint64_t per_col = (uint64_t)be.geom.W * n;
+static size_t msm_cols_per_launch(const MsmGeom& geom, size_t n) {
+  const uint64_t per_col = (uint64_t)geom.W * n;
   const uint64_t by_entries = g_msm_max_entries / per_col;
-  uint64_t by_keys = ((1ull << 31) - 1) / be.geom.B;
+  uint64_t by_keys = ((1ull << 31) - 1) / geom.B;
   // wide windows go through the two-level sort, whose one-block scan of the coarse bins holds S2_MAX_H of them: rather
-  // than fall back to the one-level sort's scattered stores, a wider batch runs in groups of that many columns
-  if (be.geom.B > 4096) {
-    const uint64_t by_bins = S2_MAX_H / msm_sort2_geom(n, be.geom).Hc;
+  // than fall back to the one-level sort's scattered stores (which windows beyond 16 bits cannot use at all), a wider
+  // batch runs in groups of that many columns
+  if (geom.B > 4096) {
+    const uint64_t by_bins = S2_MAX_H / msm_sort2_geom(n, geom).Hc;
     if (by_bins >= 1 && by_bins < by_keys) by_keys = by_bins;
   }
   return (size_t)(by_entries < by_keys ? by_entries : by_keys);   // 0: a single column is already too long
@@ -221,7 +222,7 @@ static size_t msm_cols_per_launch(const BasesEntry& be, size_t n) {
 int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_scalars, size_t first_base, size_t n,
                    size_t col_stride, size_t m, void* d_out, bool affine_out, hipStream_t stream,
                    const BasesEntry* const* per_column) {
-  const size_t group = msm_cols_per_launch(be, n);
+  const size_t group = msm_cols_per_launch(be.geom, n);
   if (group == 0) return H2_EINVAL;
   // columns with their own bases: one launch only (they must share the registered length, hence the geometry)
   const void* col_tables[MSM_MAX_MULTI];
@@ -1054,6 +1055,13 @@ extern "C" int h2_selftest_msm_check(int curve, size_t n_bases, size_t n, size_t
   const CurveOps* ops = ops_of(curve);
   if (!ops || n == 0 || m == 0 || n > n_bases) return H2_EINVAL;
   const MsmGeom g = msm_geometry(n_bases, ops->scalar_bits);
+  // as msm_device_run: a batch wider than one launch takes runs in column groups; the first (widest) group is checked
+  const size_t group = msm_cols_per_launch(g, n);
+  if (group == 0) return H2_EINVAL;
+  if (m > group) {
+    if (col_stride < n) { g_h2.last_error = "msm launch geometry: col_stride >= n"; return H2_EINVAL; }
+    m = group;
+  }
   const MsmWorkspace ws = msm_workspace(n, m, g, guard ? 256u : 0u, n_bases);
   if (out) {
     out[0] = g.c; out[1] = g.W; out[2] = g.B; out[3] = ws.sort2 ? ws.s2.tile : ws.tile;

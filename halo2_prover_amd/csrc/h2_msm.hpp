@@ -59,7 +59,8 @@ constexpr uint32_t MSM_HOT_SEG = 128;     // pieces summed by one wave of msm_ho
 constexpr uint32_t MSM_NOT_HOT = 0xFFFFFFFFu;
 constexpr uint32_t MSM_SORT_THREADS = 1024;   // block size of the digits / scatter kernels
 constexpr uint32_t MSM_CHUNK_WAVES = 3;   // resident waves per SIMD of the accumulate kernel (159 VGPRs)
-constexpr uint32_t MSM_MAX_C = 16;        // B*4 bytes of LDS histogram must fit one CU: 2^15 * 4 = 128 KiB
+constexpr uint32_t MSM_MAX_C_ONE_LEVEL = 16;   // one-level sort: B*4 bytes of LDS histogram must fit one CU: 2^15 * 4 = 128 KiB
+constexpr uint32_t MSM_MAX_C = 19;        // two-level sort: 1024 coarse bins x 256 fine buckets per column
 
 struct MsmGeom {
   uint32_t c;        // widest window, bits
@@ -80,6 +81,11 @@ inline MsmGeom msm_geometry(size_t n, uint32_t nbits) {
   // faster the fixed costs weigh more -- at 2^16 c = 11 / 12 / 13 / 14 give 2.93 / 2.69 / 2.73 / 2.85 ms per step,
   // tools/sweep_c.sh)
   int c = (int)lg - (lg <= 15 ? 3 : 4);
+  // from 2^21 terms the widest window the two-level sort reaches (19 bits: 14 windows instead of 16, 2^18 buckets per
+  // column) pays for its tail: measured -3% at 2^21, -8% at 2^22, -13% at 2^23, -9% for 8 columns of 2^24
+  // (profiles/r03_sweep_cwide.log; 17 and 18 bits keep 16 / 15 windows and do not); at 2^20 the tail costs more than the
+  // eighth of the additions it saves
+  c = lg <= 20 ? std::min(c, 16) : 19;
   c = tune_int("H2_TUNE_C", c);             // tuning builds only (h2_tune.hpp)
   if (c < 6) c = 6;
   if (c > (int)MSM_MAX_C) c = (int)MSM_MAX_C;
@@ -905,7 +911,7 @@ __device__ __forceinline__ Xyzz29<CV> xyzz29_pick(uint32_t dig, const Xyzz29<CV>
 // The whole chain is ONE loop around one doubling and one addition (a little program counter decides what each step
 // does): written as straight-line code the kernel was 180 KB -- every inlined addition is ~24 KB -- and each copy ran
 // exactly once, from a cold instruction cache (4.9 us against 3.6 us for an addition; tools/microbench_tail.hip).
-constexpr uint32_t MSM_FINAL_MAX_BLOCKS = 32;
+constexpr uint32_t MSM_FINAL_MAX_BLOCKS = 64;      // 2^18 buckets: 512 row items + 511 column items, 16 per block
 H2_HD uint32_t msm_final_row_blocks(uint32_t log_b, uint32_t lb) { return ((1u << (log_b - lb)) + 15u) / 16u; }
 H2_HD uint32_t msm_final_blocks(uint32_t log_b, uint32_t lb) {
   return msm_final_row_blocks(log_b, lb) + ((1u << lb) - 1u + 15u) / 16u;
@@ -925,7 +931,8 @@ msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x MSM_FINA
   const uint32_t* src = rc + XYZZ29_WORDS * ((size_t)col * (rows + cols));
   const uint32_t i = (fam ? blockIdx.x - nb_row : blockIdx.x) * 16 + quad;   // this quad's item
   const uint32_t n_weigh = 3 * ndig - 1;                         // double, add x, (double, double, add)*
-  const uint32_t n_tree = n_weigh + 4, n_all = n_tree + 5;
+  const uint32_t n_more = nb > 16 ? (nb - 1) / 16 : 1;           // partials beyond the first per quad of the last block
+  const uint32_t n_tree = n_weigh + 4, n_all = n_tree + n_more + 4;
   P x = P::identity(), x2 = P::identity(), x3 = P::identity();
   uint32_t k = 0;
   if (i < cnt) {
@@ -951,11 +958,12 @@ msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x MSM_FINA
       const uint32_t d = 32u >> (pc - n_weigh);
       o = xyzz_shfl_down(r, d);
       wanted = lane < d;
-    } else if (pc == n_tree) {
-      // the last block: every quad holds partial `quad` and now adds partial `quad + 16`
-      if (quad + 16 < nb) o = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_MAX_BLOCKS + quad + 16));
+    } else if (pc < n_tree + n_more) {
+      // the last block: every quad holds partial `quad` and now adds partials `quad + 16`, `quad + 32`, ...
+      const uint32_t j = quad + 16 * (pc - n_tree + 1);
+      if (j < nb) o = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_MAX_BLOCKS + j));
     } else {
-      const uint32_t d = 32u >> (pc - n_tree - 1);
+      const uint32_t d = 32u >> (pc - n_tree - n_more);
       o = xyzz_shfl_down(r, d);
       wanted = lane < d;
     }
@@ -1378,6 +1386,7 @@ inline const char* msm_check(const MsmWorkspace& ws, const MsmGeom& g, size_t n,
     MSM_REQUIRE(ws.regions[r].off + ws.regions[r].bytes + ws.guard <= ws.regions[r + 1].off);
   MSM_REQUIRE(ws.regions[ws.n_regions - 1].off + ws.regions[ws.n_regions - 1].bytes + ws.guard <= ws.total);
   MSM_REQUIRE(g.W >= 1 && g.W <= MSM_MAX_WINDOWS && g.B == (1u << (g.c - 1)) && g.c <= MSM_MAX_C);
+  MSM_REQUIRE(ws.sort2 || g.c <= MSM_MAX_C_ONE_LEVEL);                    // the one-level sort's LDS histogram
   MSM_REQUIRE((uint64_t)g.W * n_bases < (1ull << 31));                  // an entry is w * n_bases + i below the sign bit
   MSM_REQUIRE(ws.K == m * (size_t)g.B && ws.E == m * (size_t)g.W * n);
   MSM_REQUIRE(ws.E < (1ull << 31) && ws.K < (1ull << 31));
@@ -1454,7 +1463,7 @@ msm_guard_check_kernel(const uint8_t* __restrict__ arena, MsmWorkspace ws, uint3
 template <class CV>
 inline hipError_t msm_kernel_setup() {
   hipError_t e;
-  const int lds = (int)((1u << (MSM_MAX_C - 1)) * 4);
+  const int lds = (int)((1u << (MSM_MAX_C_ONE_LEVEL - 1)) * 4);
   if ((e = hipFuncSetAttribute((const void*)msm_digits_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)msm_scatter_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)msm_scatter_staged_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)) != hipSuccess) return e;

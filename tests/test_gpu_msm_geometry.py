@@ -55,6 +55,7 @@ SHAPES = [
     ("bn254", 1 << 18, 1 << 18, 1, (0,)),               # two-level sort (8192 buckets)
     ("pallas", 1 << 18, (1 << 18) - 77, 3, (2,)),
     ("bn254", 300001, 299999, 2, (1,)),
+    ("bn254", 1 << 21, (1 << 21) - 3, 2, (1,)),         # 19-bit windows: 2^18 buckets = 1024 coarse bins x 256 fine
     ("pallas", 1 << 18, 1 << 18, 9, (0, 7, 8)),         # 9 columns x 1024 coarse bins > 8192: two launches (8 + 1) of the two-level sort
 ]
 

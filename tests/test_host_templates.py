@@ -145,7 +145,7 @@ def test_signed_digit_decomposition_reconstructs_the_scalar(lib, name):
             cbits, W, B, nbits = (int(x) for x in out[:4])
             offs = [int(x) for x in out[4 + W:4 + 2 * W]]
             widths = [int(x) for x in out[4 + 2 * W:4 + 3 * W]]
-            assert B == 1 << (cbits - 1) and nbits == f.num_bits and cbits <= 16
+            assert B == 1 << (cbits - 1) and nbits == f.num_bits and cbits <= 19
             # balanced, contiguous windows covering nbits + 1 bits
             assert offs[0] == 0 and all(offs[w + 1] == offs[w] + widths[w] for w in range(W - 1))
             assert offs[-1] + widths[-1] == nbits + 1 and max(widths) == cbits and min(widths) >= cbits - 1

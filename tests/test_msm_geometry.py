@@ -62,6 +62,8 @@ def test_the_three_sorts_are_chosen_where_designed(lib):
     assert (a["c"], a["B"], a["staged"], a["sort2"]) == (12, 2048, 1, 0)
     _, b = check(lib, 1, 1 << 20, 1 << 20, 1)
     assert (b["c"], b["W"], b["B"], b["sort2"]) == (16, 16, 32768, 1)
+    _, d = check(lib, 1, 1 << 22, 1 << 22, 3)
+    assert (d["c"], d["W"], d["B"], d["sort2"]) == (19, 14, 1 << 18, 1)
     _, c = check(lib, 1, 3000, 3000, 2)
     assert (c["staged"], c["sort2"]) == (0, 0)
 
