@@ -200,10 +200,10 @@ ntt29_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U12
   const U128* rg0 = reinterpret_cast<const U128*>(radix);
   const U128* rg1 = rg0 + (R >> 1);
   const uint32_t* rg2 = radix + 8 * (size_t)(R >> 1);
-  auto tw_get = [&](uint32_t i) {
+  auto tw_get = [&](uint32_t i, bool from_table = false) {
     U128 t0, t1;
     Fe29<FP> t;
-    if (P.tw_global) {
+    if (P.tw_global || from_table) {
       t0 = rg0[i]; t1 = rg1[i];
       t.v[8] = (int32_t)rg2[i];
     } else {
@@ -222,64 +222,7 @@ ntt29_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U12
       twl1[i] = rg1[i];
       twl2[i] = rg2[i];
     }
-  // load the tile, bit-reversing j on the way in; the API's bytes are read as they are (x 2^256 = R' form of x / 32)
-  // (four elements per thread: unrolled so that the four loads are in flight together)
-  if (!P.is_final) {
-#pragma unroll 4
-    for (uint32_t e = tid; e < RC; e += nthr) {
-      const uint32_t cc = e & (C - 1), j = e >> P.log_c;
-      const U128* g = src + 2 * (((size_t)j << in_j_shift) + cc);
-      lds_put((h2_bitrev(j, P.log_r) << P.log_c) + cc, fe29_unpack(fe_load<FP>(g)));
-    }
-  } else {
-#pragma unroll 4
-    for (uint32_t e = tid; e < RC; e += nthr) {
-      const uint32_t j = e & (R - 1), cc = e >> P.log_r;
-      const U128* g = src + 2 * (((size_t)cc << in_c_shift) + j);
-      lds_put((h2_bitrev(j, P.log_r) << P.log_c) + cc, fe29_unpack(fe_load<FP>(g)));
-    }
-  }
-  __syncthreads();
-
-  uint32_t s = 0;
-  if (P.log_r & 1) {
-    for (uint32_t w = tid; w < (RC >> 1); w += nthr) {
-      const uint32_t cc = w & (C - 1), b = w >> P.log_c;
-      const uint32_t i0 = (b << (P.log_c + 1)) + cc, i1 = i0 + C;
-      const Fe29<FP> x = lds_get(i0), y = lds_get(i1);
-      lds_put(i0, fe29_norm(fe29_add(x, y)));
-      lds_put(i1, fe29_norm(fe29_sub(x, y)));
-    }
-    __syncthreads();
-    s = 1;
-  }
-  for (; s < P.log_r; s += 2) {
-    const uint32_t h = 1u << s;
-    for (uint32_t w = tid; w < (RC >> 2); w += nthr) {
-      const uint32_t cc = w & (C - 1), b = w >> P.log_c;
-      const uint32_t pos = b & (h - 1), grp = b >> s;
-      const uint32_t i0 = (((grp << (s + 2)) + pos) << P.log_c) + cc;
-      const uint32_t step = h << P.log_c;
-      Fe29<FP> e0 = lds_get(i0), e1 = lds_get(i0 + step), e2 = lds_get(i0 + 2 * step), e3 = lds_get(i0 + 3 * step);
-      const uint32_t tb = pos << (P.log_r - 2 - s);
-      if (s != 0) {                      // s == 0: pos == 0, the twiddles of stage s and of the pair (e0, e2) are 1
-        const Fe29<FP> ta = tw_get(pos << (P.log_r - 1 - s));
-        e1 = fe29_mul(e1, ta);
-        e3 = fe29_mul(e3, ta);
-      }
-      const Fe29<FP> a0 = fe29_add(e0, e1), a1 = fe29_sub(e0, e1);
-      Fe29<FP> a2 = fe29_add(e2, e3), a3 = fe29_sub(e2, e3);
-      if (s != 0) a2 = fe29_mul(a2, tw_get(tb));
-      a3 = fe29_mul(a3, tw_get(tb + (R >> 2)));     // e2 - e3 of two stored values: limbs within +-2^29
-      lds_put(i0, fe29_norm(fe29_add(a0, a2)));
-      lds_put(i0 + step, fe29_norm(fe29_add(a1, a3)));
-      lds_put(i0 + 2 * step, fe29_norm(fe29_sub(a0, a2)));
-      lds_put(i0 + 3 * step, fe29_norm(fe29_sub(a1, a3)));
-    }
-    __syncthreads();
-  }
-
-  // write back
+  // ---- leaving the tile: element k of column cc of the tile, carry-normalised ------------------------------------------
   Fe29<FP> pl, p32;                                     // p and 32 p as limbs (32 p: the limbs of p shifted five bits up)
 #pragma unroll
   for (int i = 0; i < 9; i++) pl.v[i] = (int32_t)fe29_p<FP>(i);
@@ -292,22 +235,21 @@ ntt29_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U12
       carry = v >> 29;
     }
   }
-  const Fe29<FP> sc29 = fe29_unpack(scale29);
-  for (uint32_t e = tid; e < RC; e += nthr) {
-    const uint32_t cc = e & (C - 1), k = e >> P.log_c;
-    Fe29<FP> x = lds_get(e);
+  auto emit = [&](uint32_t k, uint32_t cc, Fe29<FP> x) {
     Fe<FP> r;
     if (!P.is_final || P.has_scale) {
       // one product: the inter-pass twiddle w^(outer * i * k) (the table's entry 0 is 1, or the constant of a scaled
       // transform) or the final pass's scale.  32p +- x is positive (|x| <= 18p) with limbs below 2^30, so the product
       // is in [0, 50 p / 128 + p) and its limbs are those of a non-negative integer below 2^256: packed as they are
-      Fe29<FP> t = sc29;
+      Fe29<FP> t;
       bool negate = false;
       if (!P.is_final) {
         const uint32_t ex = ((i_first + cc) * k) << P.log_outer;            // < n <= 2^30
         const uint32_t half_n = 1u << n_half_log;
         negate = ex >= half_n;
         t = fe29_unpack(fe_load<FP>(tw + 2 * (size_t)(negate ? ex - half_n : ex)));
+      } else {
+        t = fe29_unpack(scale29);
       }
       x = negate ? fe29_sub(p32, x) : fe29_add(p32, x);
       x = fe29_mul(x, t);
@@ -328,6 +270,118 @@ ntt29_pass_kernel(const U128* __restrict__ in, U128* __restrict__ out, const U12
     U128* g = dst + 2 * (((size_t)k << out_k_shift) + cc);
     g[0] = U128{r.v[0], r.v[1], r.v[2], r.v[3]};
     g[1] = U128{r.v[4], r.v[5], r.v[6], r.v[7]};
+  };
+  // element j of column cc of the tile, as the API's bytes (x 2^256 = the R' form of x / 32): one of the two shifts is 0
+  auto load_el = [&](uint32_t j, uint32_t cc) {
+    return fe29_unpack(fe_load<FP>(src + 2 * (((size_t)j << in_j_shift) + ((size_t)cc << in_c_shift))));
+  };
+  // one radix-4 group (two fused radix-2 stages s, s + 1) of elements e0..e3 at LDS distance `step`
+  auto radix4 = [&](Fe29<FP>& e0, Fe29<FP>& e1, Fe29<FP>& e2, Fe29<FP>& e3, uint32_t s, uint32_t pos) {
+    if (s != 0) {                        // s == 0: pos == 0, the twiddles of stage s and of the pair (e0, e2) are 1
+      const Fe29<FP> ta = tw_get(pos << (P.log_r - 1 - s));
+      e1 = fe29_mul(e1, ta);
+      e3 = fe29_mul(e3, ta);
+    }
+    const uint32_t tb = pos << (P.log_r - 2 - s);
+    const Fe29<FP> a0 = fe29_add(e0, e1), a1 = fe29_sub(e0, e1);
+    Fe29<FP> a2 = fe29_add(e2, e3), a3 = fe29_sub(e2, e3);
+    if (s != 0) a2 = fe29_mul(a2, tw_get(tb));
+    // e2 - e3 of two stored values: limbs within +-2^29.  (s == 0 is the stage fused with the tile load: it runs before
+    // the block's first barrier, when the LDS copy of the twiddles is still being written -- its one twiddle, the
+    // fourth root of unity, comes from the table itself)
+    a3 = fe29_mul(a3, tw_get(tb + (R >> 2), s == 0));
+    e0 = fe29_norm(fe29_add(a0, a2));
+    e1 = fe29_norm(fe29_add(a1, a3));
+    e2 = fe29_norm(fe29_sub(a0, a2));
+    e3 = fe29_norm(fe29_sub(a1, a3));
+  };
+
+  // Round 3 (late): the FIRST stage works on the elements as they arrive from HBM and the LAST one hands its results to
+  // the exit code in registers -- two of a 1024-row tile's six LDS round trips and two of its six barriers are gone.
+  // The thread that owns rows t, t + R/4, t + R/2, t + 3R/4 of the tile (its bit-reversed positions are the four
+  // neighbours 4 brev(t) + 0..3) loads them -- consecutive threads still read consecutive addresses, as before.
+  // Tiles of fewer than 8 rows (transforms of 2 or 4 elements) keep the plain sequence: load, stages, write back.
+  const bool fused = P.log_r >= 3;
+  uint32_t s = 0;
+  if (fused) {
+    if (P.log_r & 1) {
+      const uint32_t lq = P.log_r - 1;                   // pairs (t, t + R/2): one radix-2 stage, twiddle 1
+      for (uint32_t w = tid; w < (RC >> 1); w += nthr) {
+        const uint32_t cc = P.is_final ? w >> lq : w & (C - 1), t = P.is_final ? w & ((1u << lq) - 1) : w >> P.log_c;
+        const Fe29<FP> x = load_el(t, cc), y = load_el(t + (R >> 1), cc);
+        const uint32_t i0 = (h2_bitrev(t, lq) << (P.log_c + 1)) + cc;
+        lds_put(i0, fe29_norm(fe29_add(x, y)));
+        lds_put(i0 + C, fe29_norm(fe29_sub(x, y)));
+      }
+      s = 1;
+    } else {
+      const uint32_t lq = P.log_r - 2;
+      for (uint32_t w = tid; w < (RC >> 2); w += nthr) {
+        const uint32_t cc = P.is_final ? w >> lq : w & (C - 1), t = P.is_final ? w & ((1u << lq) - 1) : w >> P.log_c;
+        // LDS neighbours q = 0..3 of 4 brev(t) hold rows t + brev2(q) R/4
+        Fe29<FP> e0 = load_el(t, cc), e1 = load_el(t + (R >> 1), cc), e2 = load_el(t + (R >> 2), cc),
+                 e3 = load_el(t + 3 * (R >> 2), cc);
+        radix4(e0, e1, e2, e3, 0, 0);
+        const uint32_t i0 = (h2_bitrev(t, lq) << (P.log_c + 2)) + cc;
+        lds_put(i0, e0);
+        lds_put(i0 + C, e1);
+        lds_put(i0 + 2 * C, e2);
+        lds_put(i0 + 3 * C, e3);
+      }
+      s = 2;
+    }
+    __syncthreads();
+  } else {
+    // load the tile, bit-reversing j on the way in
+    for (uint32_t e = tid; e < RC; e += nthr) {
+      const uint32_t j = P.is_final ? e & (R - 1) : e >> P.log_c, cc = P.is_final ? e >> P.log_r : e & (C - 1);
+      lds_put((h2_bitrev(j, P.log_r) << P.log_c) + cc, load_el(j, cc));
+    }
+    __syncthreads();
+    if (P.log_r & 1) {
+      for (uint32_t w = tid; w < (RC >> 1); w += nthr) {
+        const uint32_t cc = w & (C - 1), b = w >> P.log_c;
+        const uint32_t i0 = (b << (P.log_c + 1)) + cc, i1 = i0 + C;
+        const Fe29<FP> x = lds_get(i0), y = lds_get(i1);
+        lds_put(i0, fe29_norm(fe29_add(x, y)));
+        lds_put(i1, fe29_norm(fe29_sub(x, y)));
+      }
+      __syncthreads();
+      s = 1;
+    }
+  }
+  const uint32_t s_end = fused ? P.log_r - 2 : P.log_r;
+  for (; s < s_end; s += 2) {
+    const uint32_t h = 1u << s;
+    for (uint32_t w = tid; w < (RC >> 2); w += nthr) {
+      const uint32_t cc = w & (C - 1), b = w >> P.log_c;
+      const uint32_t pos = b & (h - 1), grp = b >> s;
+      const uint32_t i0 = (((grp << (s + 2)) + pos) << P.log_c) + cc;
+      const uint32_t step = h << P.log_c;
+      Fe29<FP> e0 = lds_get(i0), e1 = lds_get(i0 + step), e2 = lds_get(i0 + 2 * step), e3 = lds_get(i0 + 3 * step);
+      radix4(e0, e1, e2, e3, s, pos);
+      lds_put(i0, e0);
+      lds_put(i0 + step, e1);
+      lds_put(i0 + 2 * step, e2);
+      lds_put(i0 + 3 * step, e3);
+    }
+    __syncthreads();
+  }
+  if (fused) {
+    // the last double stage (s = log r - 2: one group, pos = the row): rows pos + q R/4 leave from registers
+    const uint32_t step = (R >> 2) << P.log_c;
+    for (uint32_t w = tid; w < (RC >> 2); w += nthr) {
+      const uint32_t cc = w & (C - 1), pos = w >> P.log_c;
+      const uint32_t i0 = (pos << P.log_c) + cc;
+      Fe29<FP> e0 = lds_get(i0), e1 = lds_get(i0 + step), e2 = lds_get(i0 + 2 * step), e3 = lds_get(i0 + 3 * step);
+      radix4(e0, e1, e2, e3, P.log_r - 2, pos);
+      emit(pos, cc, e0);
+      emit(pos + (R >> 2), cc, e1);
+      emit(pos + 2 * (R >> 2), cc, e2);
+      emit(pos + 3 * (R >> 2), cc, e3);
+    }
+  } else {
+    for (uint32_t e = tid; e < RC; e += nthr) emit(e >> P.log_c, e & (C - 1), lds_get(e));
   }
 }
 
