@@ -167,6 +167,9 @@ def main():
                     help="poseidon = the proof-shaped MSM+NTT mix (default); msm / ntt = one kernel family only")
     ap.add_argument("--msm-cols", type=int, default=1, help="columns per launch for --workload msm")
     ap.add_argument("--ntt-cols", type=int, default=1, help="columns per launch for --workload ntt")
+    ap.add_argument("--schedule", default="early_tail", choices=["tail", "free", "early", "early_tail", "early_split", "serial"],
+                    help="where the step's challenge-free transforms run: beside the MSM tails (default), unordered on a "
+                         "second stream, advice transforms from the step's start, or all on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proof", action="store_true", help="skip the end-to-end Poseidon proof (proof-gen ms)")
     ap.add_argument("--no-extras", action="store_true",
@@ -299,16 +302,27 @@ def main():
     ntt_bufs = build_ntt_bufs(False)
     ntt_bufs_shared = build_ntt_bufs(True) if world > 1 else ntt_bufs
     results = [None] * len(phases)
-    side_stream = torch.cuda.Stream(device=dev, priority=0)
-    side = side_stream.cuda_stream
-    ev_start, ev_side_done = torch.cuda.Event(), torch.cuda.Event()
 
-    def run_phase(i, off, mode="single", gather=False):
+    class Lane:
+        """the streams and events of one step in flight: the commit phases' stream, the transforms' second stream"""
+        def __init__(self, work, bufs):
+            self.work_stream, self.stream = work, work.cuda_stream
+            self.side_stream = torch.cuda.Stream(device=dev, priority=0)
+            self.side = self.side_stream.cuda_stream
+            self.ev_start, self.ev_side_done, self.ev_phase0 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            self.results = [None] * len(phases)
+            self.bufs = bufs
+
+    lane0 = Lane(work_stream, None)
+    lane0.results = results
+    side_stream, side = lane0.side_stream, lane0.side
+
+    def run_phase(i, off, mode="single", gather=False, lane=lane0):
         bases, m = phases[i]
-        results[i] = sharded.msm_phase_device(bases, msm_cols.data_ptr() + off * n * 32, n, m, stream,
-                                              mode=mode if multi else "single")
+        lane.results[i] = sharded.msm_phase_device(bases, msm_cols.data_ptr() + off * n * 32, n, m, lane.stream,
+                                                   mode=mode if multi else "single")
         if gather and multi:
-            sharded.all_gather_rows(results[i])             # every rank holds every rank's commitments of the phase
+            sharded.all_gather_rows(lane.results[i])        # every rank holds every rank's commitments of the phase
         return off + m
 
     def msm_phase(mode="single"):
@@ -326,37 +340,64 @@ def main():
         for name, *_ in ntts:
             run_ntt(name, stream)
 
-    def step(shared=False):
+    def step(shared=False, lane=lane0, sched=None):
         """shared = False: this rank's own step (mode "single", commitments gathered).  shared = True: one proof's job
-        spread over the ranks (columns when m % N == 0, else point ranges; NTT columns j -> rank j mod N)."""
+        spread over the ranks (columns when m % N == 0, else point ranges; NTT columns j -> rank j mod N).
+        `lane`: the streams the step is enqueued on (torch's current stream must be lane.work_stream)."""
         mode = (None if world > 1 else "range") if shared else "single"
-        bufs = ntt_bufs_shared if shared else ntt_bufs
+        bufs = ntt_bufs_shared if shared else (lane.bufs or ntt_bufs)
+        stream, side, side_stream, work_stream = lane.stream, lane.side, lane.side_stream, lane.work_stream
         if args.workload != "poseidon":
             off = 0
             for i in range(len(phases)):
-                off = run_phase(i, off, mode, gather=not shared)
+                off = run_phase(i, off, mode, not shared, lane)
             for name, *_ in ntts:
                 run_ntt(name, stream, bufs)
             return
-        # first stream: the five commit phases in Fiat-Shamir order.  Second stream: the transforms that wait for no
-        # challenge, each group queued behind the accumulate kernel of a commit phase (h2_stream_wait_msm_tail), so
-        # that it runs beside that phase's small-grid tail instead of beside its chip-filling kernel
-        ev_start.record(work_stream)
-        side_stream.wait_event(ev_start)
-        off = run_phase(0, 0, mode, not shared)  # advice
-        L.h2_stream_wait_msm_tail(side)
-        run_ntt("advice_i", side, bufs)
-        run_ntt("advice_e_a", side, bufs)
-        off = run_phase(1, off, mode, not shared)  # permutation products (exist once beta, gamma do) + random polynomial
-        L.h2_stream_wait_msm_tail(side)
-        run_ntt("advice_e_b", side, bufs)
+        # first stream: the commit phases in Fiat-Shamir order.  Second stream: the transforms that wait for no
+        # challenge.  Default placement ("early_tail"): the advice columns exist before their commitment does, so their
+        # transforms are queued from the step's start; those of the permutation products wait for the accumulate kernel
+        # of the products' own commit phase (h2_stream_wait_msm_tail) and run beside its small-grid tail
+        sched = sched or args.schedule
+        if sched == "serial":
+            off = run_phase(0, 0, mode, not shared, lane)
+            off = run_phase(1, off, mode, not shared, lane)
+            for name, *_ in ntts:
+                run_ntt(name, stream, bufs)
+            off = run_phase(2, off, mode, not shared, lane)
+            run_phase(3, off, mode, not shared, lane)
+            return
+        lane.ev_start.record(work_stream)
+        side_stream.wait_event(lane.ev_start)
+        early = sched.startswith("early")
+        if early:
+            run_ntt("advice_i", side, bufs)
+            run_ntt("advice_e_a", side, bufs)
+            if sched != "early_split":
+                run_ntt("advice_e_b", side, bufs)
+        off = run_phase(0, 0, mode, not shared, lane)  # advice
+        if sched in ("tail", "early_split"):
+            L.h2_stream_wait_msm_tail(side)
+        if sched in ("tail", "free"):
+            run_ntt("advice_i", side, bufs)
+            run_ntt("advice_e_a", side, bufs)
+        if sched == "early_split":
+            run_ntt("advice_e_b", side, bufs)
+        if sched in ("free", "early", "early_split"):   # z exists once beta, gamma (phase 0's commitments) do
+            lane.ev_phase0.record(work_stream)
+            side_stream.wait_event(lane.ev_phase0)
+        off = run_phase(1, off, mode, not shared, lane)  # permutation products (exist once beta, gamma do) + random polynomial
+        if sched in ("tail", "early_tail"):
+            L.h2_stream_wait_msm_tail(side)
+        if not early:
+            run_ntt("advice_e_b", side, bufs)
         run_ntt("z_i", side, bufs)
         run_ntt("z_e", side, bufs)
-        ev_side_done.record(side_stream)
-        work_stream.wait_event(ev_side_done)    # y is squeezed next; the quotient needs every extended column
+        lane.ev_side_done.record(side_stream)
+        work_stream.wait_event(lane.ev_side_done)    # y is squeezed next; the quotient needs every extended column
         run_ntt("h_i", stream, bufs)
-        off = run_phase(2, off, mode, not shared)  # quotient pieces
-        run_phase(3, off, mode, not shared)        # opening witnesses
+        off = run_phase(2, off, mode, not shared, lane)  # quotient pieces
+        run_phase(3, off, mode, not shared, lane)        # opening witnesses
 
     for _ in range(args.warmup):
         step()
@@ -416,6 +457,7 @@ def main():
     phases_ms = {}
     for name, fn in (("msm", msm_phase), ("ntt", ntt_phase)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()                                    # (scratch sized for this stream's calls before the clock starts)
         barrier()
         e0.record()
         for _ in range(3):
@@ -423,6 +465,40 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         phases_ms[name] = round(e0.elapsed_time(e1) / 3, 4)
+
+    # two steps in flight on the one GPU (sub-record; the line's value keeps one step at a time): even steps on the
+    # first pair of streams, odd steps on a second pair with transform buffers of its own -- the library gives every
+    # stream its own MSM / NTT scratch -- so that one step's sorts and small-grid tails run beside the other's
+    # chip-filling kernels.  Each step keeps its own Fiat-Shamir order.
+    two_in_flight = None
+    if args.workload == "poseidon" and world == 1 and not args.no_extras:
+        # (normal priority: a SECOND high-priority stream in the process left every later small kernel of the run 3-5 x
+        # slower -- 50 us for a 13 us kernel; profiles/r03_second_high_priority_stream.txt)
+        lane1 = Lane(torch.cuda.Stream(device=dev, priority=0),
+                     {k_: (b.clone(), lg, m, w) for k_, (b, lg, m, w) in ntt_bufs.items()})
+        lanes = [lane0, lane1]
+
+        def flight(count):
+            for i in range(count):
+                ln = lanes[i & 1]
+                with torch.cuda.stream(ln.work_stream):
+                    step(lane=ln, sched="early")
+        flight(4)
+        torch.cuda.synchronize()
+        # the second lane computes what the first does (same inputs): its commitments must be the first lane's
+        qf = BASE_FIELD[args.curve]
+        same = all(jac_to_affine_ints(a.cpu().numpy().view(np.uint64), qf) == jac_to_affine_ints(b.cpu().numpy().view(np.uint64), qf)
+                   for a, b in zip(lane0.results, lane1.results))
+        assert same, "two steps in flight: the lanes' commitments differ"
+        cnt = 2 * max(args.steps, 10)
+        tf = time.perf_counter()
+        flight(cnt)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - tf
+        two_in_flight = {"what": "two proof-shaped steps in flight on one GPU (alternating stream pairs, each with its own "
+                                 "scratch); throughput over %d steps" % cnt,
+                         "ms_per_step": round(dtf / cnt * 1e3, 4), "steps_per_s": cnt / dtf,
+                         "lanes_agree": same}
 
     overlap = None
     if args.workload == "poseidon":
@@ -445,6 +521,8 @@ def main():
                         "ms_per_step": phases_ms["ntt"]}
 
     ops_step = n_msm * ops_msm(n) + sum(m * ops_ntt(1 << lg) for _, lg, m, _, _ in ntts)
+    if two_in_flight:
+        two_in_flight["field_ops_per_s"] = ops_step * two_in_flight.pop("steps_per_s")
     value = world * ops_step * args.steps / dt     # every rank ran the step on its own columns: N steps' field-ops per step time
 
     # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read
@@ -563,7 +641,7 @@ def main():
             "sharded_equals_unsharded": sharded_ok, "one_proof_sharded": one_proof,
             "roofline": roofline, "roofline_ntt": roofline_ntt, "modmul_ceiling": modmul,
             "cpu_baseline": cpu, "proof_gen": proof_gen, "proof_gen_n_gpus": proof_gen_multi,
-            "phases_ms": phases_ms, "overlap": overlap, "field_ops_per_step": ops_step,
+            "phases_ms": phases_ms, "overlap": overlap, "two_steps_in_flight": two_in_flight, "field_ops_per_step": ops_step,
         }
         out.update(extras)
         print(json.dumps(out))
@@ -622,7 +700,7 @@ def step_on_curve(args, curve, dev, steps=10, warmup=2):
             ("z_i", k, 2, True), ("z_e", k + ext, 2, False), ("h_i", k + ext, 1, True)]
     bufs = {name: (torch.from_numpy(splitmix_columns(0x48324D5300000110 + j, m << lg, p).view(np.int64)).to(dev), lg, m,
                    omega(lg, inv)) for j, (name, lg, m, inv) in enumerate(ntts)}
-    ev_start, ev_side_done = torch.cuda.Event(), torch.cuda.Event()
+    ev_start, ev_side_done, ev_phase0 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
     def phase(i, off):
         bases, m = phases[i]
@@ -633,16 +711,15 @@ def step_on_curve(args, curve, dev, steps=10, warmup=2):
         buf, lg, m, w = bufs[name]
         h2.ntt_device(buf.data_ptr(), m, w, lg, curve, st)
 
-    def step():
+    def step():                                  # the headline step's default placement ("early_tail")
         ev_start.record(work_stream)
         side_stream.wait_event(ev_start)
-        off = phase(0, 0)
-        L.h2_stream_wait_msm_tail(side)
         ntt("advice_i", side)
         ntt("advice_e_a", side)
+        ntt("advice_e_b", side)
+        off = phase(0, 0)
         off = phase(1, off)
         L.h2_stream_wait_msm_tail(side)
-        ntt("advice_e_b", side)
         ntt("z_i", side)
         ntt("z_e", side)
         ev_side_done.record(side_stream)

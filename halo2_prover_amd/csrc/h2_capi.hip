@@ -85,8 +85,10 @@ DevCtx* ctx_current() {
 size_t ctx_index(const DevCtx* c) { return (size_t)(c - &g_h2.ctx[0]); }
 
 // ---- arenas ----------------------------------------------------------------------------------
+static uint64_t g_arena_growths = 0, g_arena_waits = 0;
 int arena_acquire(Arena& a, size_t want, hipStream_t s) {
   if (a.bytes < want) {
+    g_arena_growths++;
     if (a.p) {
       // rare: a larger call than any before.  Work enqueued on other streams may still use the arena.
       H2_TRY(hipDeviceSynchronize());
@@ -105,7 +107,10 @@ int arena_acquire(Arena& a, size_t want, hipStream_t s) {
     a.bytes = sz;
   }
   if (!a.ev) H2_TRY(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
-  if (a.used && a.last != s) H2_TRY(hipStreamWaitEvent(s, a.ev, 0));   // order behind the previous user
+  if (a.used && a.last != s) {                                         // order behind the previous user
+    g_arena_waits++;
+    H2_TRY(hipStreamWaitEvent(s, a.ev, 0));
+  }
   return H2_OK;
 }
 int arena_release(Arena& a, hipStream_t s) {
@@ -160,15 +165,16 @@ static int register_device(DevCtx& src, int curve, const void* d_affine, size_t 
     uint32_t* d_bad = (uint32_t*)src.div_ws.p;
     uint32_t bad = 0;
     // the table kernel's scratch (80 bytes per table entry) is the MSM workspace, idle while bases are being registered
-    rc = arena_acquire(src.msm_ws, be.table_bytes / 64 * MSM_TABLE_SCRATCH, src.stream);
+    Arena& table_ws = src.msm_ws.of(src.stream);
+    rc = arena_acquire(table_ws, be.table_bytes / 64 * MSM_TABLE_SCRATCH, src.stream);
     if (rc != H2_OK) return fail(rc);
     hipError_t e = hipMemsetAsync(d_bad, 0, 4, src.stream);
-    if (e == hipSuccess) e = ops->table_build(d_affine, be.table[si], src.msm_ws.p, (uint32_t)n, g, d_bad, src.stream);
+    if (e == hipSuccess) e = ops->table_build(d_affine, be.table[si], table_ws.p, (uint32_t)n, g, d_bad, src.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, src.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(src.stream);
     if (e != hipSuccess) return fail(dev_fail(e, "msm_table_kernel"));
     (void)arena_release(src.div_ws, src.stream);
-    (void)arena_release(src.msm_ws, src.stream);
+    (void)arena_release(table_ws, src.stream);
     if (bad) {
       g_h2.last_error = "bases: " + std::to_string(bad) + " point(s) not on the curve";
       return fail(H2_EINVAL);
@@ -241,15 +247,16 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
     const size_t mm = m - j0 < group ? m - j0 : group;
     MsmWorkspace ws = msm_workspace(n, mm, be.geom, g_msm_guard ? 256u : 0u, be.n, g_sort2_pack);
     if (ws.E >= (1ull << 31) || ws.K >= (1ull << 31)) return H2_EINVAL;
-    int rc = arena_acquire(c.msm_ws, ws.total, stream);
+    Arena& A = c.msm_ws.of(stream);
+    int rc = arena_acquire(A, ws.total, stream);
     if (rc != H2_OK) return rc;
     // every kernel's index range against the region it indexes, before anything is enqueued.  (n_bases is the
     // REGISTERED length whatever the range: a sorted entry is w * be.n + i relative to the table row of first_base)
-    if (const char* broken = msm_check(ws, be.geom, n, mm, col_stride, (uint32_t)be.n, c.msm_ws.bytes)) {
+    if (const char* broken = msm_check(ws, be.geom, n, mm, col_stride, (uint32_t)be.n, A.bytes)) {
       g_h2.last_error = std::string("msm launch geometry: ") + broken;
       return H2_EDEVICE;
     }
-    if (g_msm_guard) H2_TRY(hipMemsetAsync(c.msm_ws.p, MSM_GUARD_BYTE, ws.total, stream));
+    if (g_msm_guard) H2_TRY(hipMemsetAsync(A.p, MSM_GUARD_BYTE, ws.total, stream));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_h2.profiling) {
       if (c.prof_used == c.prof_events.size()) {
@@ -267,7 +274,7 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
     void* dst = (char*)d_out + j0 * out_sz;
     hipError_t e = ops->msm_launch(table, per_column ? col_tables : nullptr, (uint32_t)be.n,
                                    (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
-                                   mm, be.geom, (char*)c.msm_ws.p, ws, stream, ev0, ev1, (c.tail_wanted && !ev1) ? c.tail_event : nullptr,
+                                   mm, be.geom, (char*)A.p, ws, stream, ev0, ev1, (c.tail_wanted && !ev1) ? c.tail_event : nullptr,
                                    affine_out ? nullptr : dst);
     c.tail_recorded = c.tail_wanted;
     c.tail_wait = ev1 ? ev1 : c.tail_event;
@@ -278,8 +285,8 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
       H2_TRY(hipMalloc(&d_bad, ws.n_regions * 4));
       H2_TRY(hipMemsetAsync(d_bad, 0, ws.n_regions * 4, stream));
       if (g_msm_guard_poke)        // the checker's own test: one byte just behind the second region
-        H2_TRY(hipMemsetAsync((char*)c.msm_ws.p + ws.regions[1].off + ws.regions[1].bytes, 0, 1, stream));
-      hipLaunchKernelGGL(msm_guard_check_kernel, dim3(ws.n_regions), dim3(256), 0, stream, (const uint8_t*)c.msm_ws.p, ws, d_bad);
+        H2_TRY(hipMemsetAsync((char*)A.p + ws.regions[1].off + ws.regions[1].bytes, 0, 1, stream));
+      hipLaunchKernelGGL(msm_guard_check_kernel, dim3(ws.n_regions), dim3(256), 0, stream, (const uint8_t*)A.p, ws, d_bad);
       H2_TRY(hipMemcpyAsync(bad.data(), d_bad, ws.n_regions * 4, hipMemcpyDeviceToHost, stream));
       H2_TRY(hipStreamSynchronize(stream));
       (void)hipFree(d_bad);
@@ -293,10 +300,10 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
         }
     }
     if (affine_out) {
-      e = ops->to_affine((char*)c.msm_ws.p + ws.off_tree2, dst, (uint32_t)mm, stream);
+      e = ops->to_affine((char*)A.p + ws.off_tree2, dst, (uint32_t)mm, stream);
       if (e != hipSuccess) return dev_fail(e, "msm finish kernel");
     }
-    rc = arena_release(c.msm_ws, stream);
+    rc = arena_release(A, stream);
     if (rc != H2_OK) return rc;
   }
   return H2_OK;
@@ -356,14 +363,16 @@ int ntt_enqueue(DevCtx& c, int curve, void* d_a, size_t m, const uint64_t omega[
   if (rc != H2_OK) return rc;
   NttPlan pl = ntt_make_plan(log_n);
   void* scratch = nullptr;
+  Arena* A = nullptr;
   if (pl.npass > 1) {
-    rc = arena_acquire(c.ntt_ws, m * ((size_t)32 << log_n), stream);
+    A = &c.ntt_ws.of(stream);
+    rc = arena_acquire(*A, m * ((size_t)32 << log_n), stream);
     if (rc != H2_OK) return rc;
-    scratch = c.ntt_ws.p;
+    scratch = A->p;
   }
   hipError_t e = ops->ntt_launch(d_a, scratch, tw, log_n, m, stream, scale);
   if (e != hipSuccess) return dev_fail(e, "ntt_launch");
-  if (pl.npass > 1) return arena_release(c.ntt_ws, stream);
+  if (A) return arena_release(*A, stream);
   return H2_OK;
 }
 
@@ -473,8 +482,8 @@ int h2_shutdown(void) {
     for (auto& kv : g_h2.bases)
       if (kv.second.table[i]) (void)hipFree(kv.second.table[i]);
     for (auto& t : c.twiddles) (void)hipFree(t.tw);
-    arena_free(c.msm_ws);
-    arena_free(c.ntt_ws);
+    for (Arena& a : c.msm_ws.slot) arena_free(a);
+    for (Arena& a : c.ntt_ws.slot) arena_free(a);
     arena_free(c.stage);
     arena_free(c.div_ws);
     for (auto& pe : c.prof_events) {
@@ -929,11 +938,12 @@ int h2_fft_group_device(h2_curve_t curve, void* d_points_jac, const uint64_t ome
   if (!curve_ok((int)curve) || !d_points_jac || !omega || log_n > 26) return H2_EINVAL;
   if (log_n == 0) return H2_OK;
   const CurveOps* ops = ops_of((int)curve);
-  int rc = arena_acquire(k.c->msm_ws, ops->group_fft_scratch(log_n), k.stream);      // the MSM workspace, idle here
+  Arena& A = k.c->msm_ws.of(k.stream);
+  int rc = arena_acquire(A, ops->group_fft_scratch(log_n), k.stream);      // the MSM workspace, idle here
   if (rc != H2_OK) return rc;
-  hipError_t e = ops->group_fft(d_points_jac, d_points_jac, k.c->msm_ws.p, omega, log_n, k.stream);
+  hipError_t e = ops->group_fft(d_points_jac, d_points_jac, A.p, omega, log_n, k.stream);
   if (e != hipSuccess) return dev_fail(e, "group fft kernels");
-  return arena_release(k.c->msm_ws, k.stream);
+  return arena_release(A, k.stream);
 }
 
 int h2_fft_group(h2_curve_t curve, uint64_t* points_jac, const uint64_t omega[4], uint32_t log_n) {
@@ -1071,6 +1081,18 @@ extern "C" int h2_selftest_msm_check(int curve, size_t n_bases, size_t n, size_t
     g_h2.last_error = std::string("msm launch geometry: ") + broken;
     return H2_EINVAL;
   }
+  return H2_OK;
+}
+// scratch arenas of the current context: out = {allocations (first use or growth), cross-stream hand-overs (event waits),
+// MSM slots taken over, NTT slots taken over}
+extern "C" int h2_selftest_arena_stats(uint64_t out[4]) {
+  std::lock_guard<std::recursive_mutex> lk(g_h2_mu);
+  DevCtx* c = g_h2.ready ? ctx_current() : nullptr;
+  if (!c || !out) return H2_EINVAL;
+  out[0] = g_arena_growths;
+  out[1] = g_arena_waits;
+  out[2] = c->msm_ws.takeovers;
+  out[3] = c->ntt_ws.takeovers;
   return H2_OK;
 }
 // host only: the sort's block -> (column, tile) mapping for `tiles` tiles per column and m columns: every block of

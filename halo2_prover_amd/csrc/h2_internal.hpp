@@ -26,6 +26,37 @@ struct Arena {
   bool used = false;
 };
 
+// Scratch that a launch sequence owns from its first kernel to its last (the MSM workspace, the NTT's second buffer): one
+// arena per stream for up to H2_ARENA_SLOTS streams, so that launch sequences enqueued on different streams run side by
+// side (two proofs in flight on one GPU: bench.py's `two_steps_in_flight`).  A further stream takes over the slot that
+// has been idle longest; arena_acquire orders it behind that slot's previous user (an event wait), as it ordered every
+// stream behind every other before round 3.
+constexpr int H2_ARENA_SLOTS = 4;
+struct ArenaSet {
+  Arena slot[H2_ARENA_SLOTS];
+  hipStream_t owner[H2_ARENA_SLOTS] = {};
+  bool owned[H2_ARENA_SLOTS] = {};
+  uint64_t used_at[H2_ARENA_SLOTS] = {};
+  uint64_t clock = 0, takeovers = 0;
+  Arena& of(hipStream_t s) {
+    int pick = -1;
+    for (int i = 0; i < H2_ARENA_SLOTS && pick < 0; i++)
+      if (owned[i] && owner[i] == s) pick = i;
+    for (int i = 0; i < H2_ARENA_SLOTS && pick < 0; i++)
+      if (!owned[i]) pick = i;
+    if (pick < 0) {
+      pick = 0;
+      for (int i = 1; i < H2_ARENA_SLOTS; i++)
+        if (used_at[i] < used_at[pick]) pick = i;
+      takeovers++;
+    }
+    owned[pick] = true;
+    owner[pick] = s;
+    used_at[pick] = ++clock;
+    return slot[pick];
+  }
+};
+
 struct TwiddleEntry {
   int field;
   uint32_t log_n;
@@ -41,7 +72,8 @@ struct DevCtx {
   hipStream_t stream = nullptr;   // the library's own (blocking) stream on this device
   hipStream_t side_stream = nullptr;   // the C++ prover's second stream (transforms beside the MSM tails), created on demand
   hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
-  Arena msm_ws, ntt_ws, stage, div_ws;
+  ArenaSet msm_ws, ntt_ws;
+  Arena stage, div_ws;
   hipEvent_t shard_ev = nullptr;     // C++ prover: this context's share of a commit phase is done / the columns are final
   hipEvent_t tail_event = nullptr;   // recorded behind the accumulate kernel of the latest MSM (h2_stream_wait_msm_tail)
   hipEvent_t tail_wait = nullptr;    // the event to wait on for that: tail_event, or the profiling stop event of the

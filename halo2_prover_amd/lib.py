@@ -90,6 +90,7 @@ SELFTEST_SYMBOLS = {
     "h2_selftest_msm_tiles": (_I, [_U32, _U32]),
     "h2_selftest_msm_guard": (_I, [_I]),
     "h2_selftest_msm_guard_report": (_I, [_P, _P, _Z]),
+    "h2_selftest_arena_stats": (_I, [_P]),
 }
 
 # the RNG callback of the product surface: void (*)(void* ctx, uint8_t* out, size_t n)

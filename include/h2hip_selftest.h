@@ -72,6 +72,10 @@ uint64_t h2_selftest_sharded_commits(void);
 /* rows per context from which the C++ prover spreads a commit phase over the contexts (default 1024; 0 restores it) */
 int h2_selftest_set_shard_min_rows(size_t rows);
 int h2_selftest_host(int what, const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* out_len);
+/* scratch arenas of the current context: out = {allocations, cross-stream hand-overs (event waits), MSM slots taken
+ * over by a further stream, NTT slots taken over} since h2_init */
+int h2_selftest_arena_stats(uint64_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif
