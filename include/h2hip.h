@@ -26,10 +26,13 @@
  * from several host threads are safe.  Host-pointer entry points run on the library's own stream of each device and
  * return when the result is in host memory.  The *_device entry points enqueue on the caller's `stream` (a
  * hipStream_t; NULL = the library's stream, a blocking stream, i.e. ordered against the legacy null stream that
- * PyTorch uses by default) and return without synchronising.  Different calls may use different streams: the
- * library's scratch arenas (one for the MSM, one for the multi-pass NTT, one for the division / prefix scans)
- * remember their last user and make the next call on another stream wait for it with an event, so results are
- * correct whatever streams are mixed; an MSM and an NTT on two streams overlap, two MSMs on two streams serialise.
+ * PyTorch uses by default) and return without synchronising.  Different calls may use different streams.  The MSM
+ * workspace and the multi-pass NTT's second buffer exist once per stream for up to four streams per device: MSMs (or
+ * NTTs) enqueued on different streams run side by side -- two proofs in flight on one GPU, DESIGN.md section 5 -- and a
+ * fifth stream takes over the scratch that has been idle longest, behind an event wait.  The division / prefix-scan
+ * scratch is one per device: it remembers its last user and makes a call on another stream wait for it.  Results are
+ * correct whatever streams are mixed (tests/test_gpu_multi.py).  Scratch is sized by the largest call seen on its
+ * stream and kept until h2_shutdown.
  * The caller orders its own producers / consumers of the device buffers it passes, as with any HIP library.
  *
  * Devices.  h2_init(device) binds the process to one GPU (one process per GPU under torch.distributed / RCCL is how
