@@ -460,11 +460,11 @@ def main():
         fn()                                    # (scratch sized for this stream's calls before the clock starts)
         barrier()
         e0.record()
-        for _ in range(3):
+        for _ in range(10):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        phases_ms[name] = round(e0.elapsed_time(e1) / 3, 4)
+        phases_ms[name] = round(e0.elapsed_time(e1) / 10, 4)
 
     # two steps in flight on the one GPU (sub-record; the line's value keeps one step at a time): even steps on the
     # first pair of streams, odd steps on a second pair with transform buffers of its own -- the library gives every

@@ -458,6 +458,98 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* block_sums, uint32_t* offs
   }
 }
 
+// Entries per accumulate thread, decided ON THE DEVICE from the number of entries the sort actually produced
+// (E = offsets[K]): the host sizes T for the worst case (every window of every scalar non-zero), but the columns of a
+// real proof are mostly zeros (a Poseidon witness is ~60 rows of 65 536, fixed columns likewise): with the host's T a
+// sparse launch put 64 dependent additions on each of a few hundred threads of an idle GPU (1.9 ms for keygen's 16
+// sparse columns).  Every kernel that cuts the sorted list into chunks calls this with the same arguments.  Never
+// above the host's T, so the chunk count stays within the arrays sized for it.
+__device__ __forceinline__ uint32_t msm_effective_t(uint32_t E, uint32_t t_host) {
+  uint32_t t = (E + MSM_CHUNK_WAVES * 65536u - 1) / (MSM_CHUNK_WAVES * 65536u);
+  if (t < 8) t = 8;
+  return t < t_host ? t : t_host;
+}
+
+// Degenerate columns (a permutation grand product that is 1 on almost every row, an all-ones selector) put tens of
+// thousands of entries into one bucket.  The chunk kernel does not care -- every thread still adds T entries -- but
+// the bucket then has thousands of pieces.  One thread per key: keys with more than MSM_HOT_SPAN pieces reserve
+// ceil(span / MSM_HOT_SEG) slots and emit one task per slot.
+// The same pass gives every chunk its first key: chunk_first[j] = key for the chunks that START inside the key's
+// list (each chunk start lies in exactly one non-empty list, so every slot below ceil(E / T) gets one writer).
+// It needs the scan's `offsets` only -- like the scatter, which does not need IT: every block of the staged scatter kernel
+// first runs this pass for its share of the keys (MsmKeysArgs::keys_per_block: a few dozen keys on its first wave
+// while the other waves start on the scatter), one launch and its ~9 us of stream time less per MSM.  (As blocks of
+// their own in that launch -- in front or behind -- the keys blocks each took a CU's LDS and pushed eight scatter blocks
+// into a second round: no gain.)  The other sorts launch msm_keys_kernel.  A block covers keys [key_lo, key_lo +
+// key_count); `long_key`: blockDim.x + 1 words of LDS.  One block also stores the per-column table pointers of a
+// multi-table launch.
+constexpr uint32_t MSM_MAX_MULTI = 16;    // columns of a launch that may each bring their own bases
+struct MsmTableList {
+  const U128* t[MSM_MAX_MULTI];
+};
+struct MsmKeysArgs {
+  uint32_t* chunk_first;
+  uint32_t* hot_slot;
+  uint32_t* tasks;          // 2 words each: key, segment
+  uint32_t* task_count;
+  uint32_t max_tasks, T_host;
+  uint32_t keys_per_block;  // staged scatter: every block runs the keys pass for this many keys first (0: it does not)
+  uint32_t n_tables;        // per-column tables to store (0: the launch has one table)
+  const U128** tables_dst;
+  MsmTableList tables;
+};
+__device__ __forceinline__ void msm_keys_block(const uint32_t* __restrict__ offsets, size_t K, const MsmKeysArgs& A, size_t key_lo,
+                                               uint32_t key_count /* <= blockDim.x */, bool store_tables,
+                                               uint32_t* long_key /* LDS: blockDim.x + 1 words */) {
+  // long lists (degenerate columns: tens of thousands of chunks under one key) are filled by the whole block
+  uint32_t* n_long = long_key + blockDim.x;
+  const uint32_t T = msm_effective_t(offsets[K], A.T_host);
+  if (threadIdx.x == 0) *n_long = 0;
+  if (store_tables && threadIdx.x < A.n_tables) A.tables_dst[threadIdx.x] = A.tables.t[threadIdx.x];
+  __syncthreads();
+  const size_t key = key_lo + threadIdx.x;
+  const bool live = threadIdx.x < key_count && key < K;
+  const uint32_t s = live ? offsets[key] : 0, e = live ? offsets[key + 1] : 0;
+  if (live) {
+    const uint32_t j0 = (s + T - 1) / T;
+    const uint64_t j1 = ((uint64_t)e + T - 1) / T;             // chunks j0 .. j1-1 start inside [s, e)
+    if (j1 > (uint64_t)j0 + 64) long_key[atomicAdd(n_long, 1u)] = (uint32_t)key;
+    else
+      for (uint32_t j = j0; j < j1; j++) A.chunk_first[j] = (uint32_t)key;
+  }
+  __syncthreads();
+  const uint32_t nl = *n_long;
+  for (uint32_t q = 0; q < nl; q++) {
+    const uint32_t lk = long_key[q];
+    const uint32_t ls = offsets[lk], le = offsets[lk + 1];
+    const uint64_t j1 = ((uint64_t)le + T - 1) / T;
+    for (uint64_t j = (uint64_t)(ls + T - 1) / T + threadIdx.x; j < j1; j += blockDim.x) A.chunk_first[j] = lk;
+  }
+  if (!live) return;
+  uint32_t slot = MSM_NOT_HOT;
+  if (e > s) {
+    const uint32_t span = (e - 1) / T - s / T + 1;
+    if (span > MSM_HOT_SPAN) {
+      const uint32_t nseg = (span + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
+      const uint32_t first = atomicAdd(A.task_count, nseg);
+      if (first + nseg <= A.max_tasks) {     // cannot fail by construction (see msm_workspace); stay in bounds anyway
+        slot = first;
+        for (uint32_t q = 0; q < nseg; q++) {
+          A.tasks[2 * (first + q)] = (uint32_t)key;
+          A.tasks[2 * (first + q) + 1] = q;
+        }
+      }
+    }
+  }
+  A.hot_slot[key] = slot;
+}
+constexpr uint32_t MSM_KEYS_THREADS = 256;
+static __global__ void __launch_bounds__(MSM_KEYS_THREADS)
+msm_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, MsmKeysArgs A) {
+  __shared__ uint32_t long_key[MSM_KEYS_THREADS + 1];
+  msm_keys_block(offsets, K, A, (size_t)blockIdx.x * blockDim.x, blockDim.x, blockIdx.x == 0, long_key);
+}
+
 // ---- scatter: same tiling as the digits kernel, which already reserved the tile's range in every bucket's list:
 // LDS cursors = list start + tile base, then one LDS atomic and one store per entry.
 // sorted_ref[pos] = (w * n_bases + i) | sign.  Only ONE word per entry is written: every scattered 4-byte store
@@ -511,7 +603,7 @@ msm_scatter_staged_kernel(const U128* __restrict__ scalars, const uint32_t* __re
                           const uint32_t* __restrict__ gcounts, const uint32_t* __restrict__ tile_base,
                           const uint32_t* __restrict__ tile_hist, uint32_t* __restrict__ sorted_ref, uint32_t n,
                           size_t col_stride /* elements */, uint32_t n_bases, uint32_t tile, uint32_t tiles, uint32_t m,
-                          MsmGeom g, uint32_t stage_cap /* entries the staging area holds = tile * W */) {
+                          MsmGeom g, uint32_t stage_cap /* entries the staging area holds = tile * W */, MsmKeysArgs keys) {
   using S = typename CV::Scalar;
   extern __shared__ uint32_t hist[];
   __shared__ uint32_t wave_sum[16];
@@ -523,6 +615,11 @@ msm_scatter_staged_kernel(const U128* __restrict__ scalars, const uint32_t* __re
   const MsmTileId id = msm_tile_id(tiles, m);
   if (!id.live) return;
   const uint32_t col = id.col;
+  if (keys.keys_per_block) {                              // this block's share of the keys pass (msm_keys_block)
+    const uint32_t v = col * tiles + id.tile;
+    msm_keys_block(offsets, (size_t)m * g.B, keys, (size_t)v * keys.keys_per_block, keys.keys_per_block, v == 0, hist);
+    __syncthreads();                                      // the pass is done with the LDS the scatter uses from here on
+  }
   const uint32_t* tb = tile_base + ((size_t)col * tiles + id.tile) * g.B;
   const uint32_t* th = tile_hist + ((size_t)col * tiles + id.tile) * g.B;
   const uint32_t* gc = gcounts + (size_t)col * g.B;
@@ -569,18 +666,6 @@ msm_scatter_staged_kernel(const U128* __restrict__ scalars, const uint32_t* __re
   __syncthreads();
   const uint32_t total = min(total_s, stage_cap);
   for (uint32_t j = threadIdx.x; j < total; j += blockDim.x) sorted_ref[delta[sbkt[j]] + j] = sref[j];
-}
-
-// Entries per accumulate thread, decided ON THE DEVICE from the number of entries the sort actually produced
-// (E = offsets[K]): the host sizes T for the worst case (every window of every scalar non-zero), but the columns of a
-// real proof are mostly zeros (a Poseidon witness is ~60 rows of 65 536, fixed columns likewise): with the host's T a
-// sparse launch put 64 dependent additions on each of a few hundred threads of an idle GPU (1.9 ms for keygen's 16
-// sparse columns).  Every kernel that cuts the sorted list into chunks calls this with the same arguments.  Never
-// above the host's T, so the chunk count stays within the arrays sized for it.
-__device__ __forceinline__ uint32_t msm_effective_t(uint32_t E, uint32_t t_host) {
-  uint32_t t = (E + MSM_CHUNK_WAVES * 65536u - 1) / (MSM_CHUNK_WAVES * 65536u);
-  if (t < 8) t = 8;
-  return t < t_host ? t : t_host;
 }
 
 // ---- accumulate: every thread adds T consecutive sorted entries ---------------------------------
@@ -686,58 +771,6 @@ __device__ __forceinline__ Xyzz29<CV> msm_piece(const uint32_t* __restrict__ hea
   const uint32_t j = j0 + p;
   const uint32_t* src = (p == 0 && s != j0 * T) ? tail : head;
   return xyzz29_load<CV>(src + XYZZ29_WORDS * (size_t)j);
-}
-
-// Degenerate columns (a permutation grand product that is 1 on almost every row, an all-ones selector) put tens of
-// thousands of entries into one bucket.  The chunk kernel does not care -- every thread still adds T entries -- but
-// the bucket then has thousands of pieces.  One thread per key: keys with more than MSM_HOT_SPAN pieces reserve
-// ceil(span / MSM_HOT_SEG) slots and emit one task per slot.
-// The same pass gives every chunk its first key: chunk_first[j] = key for the chunks that START inside the key's
-// list (each chunk start lies in exactly one non-empty list, so every slot below ceil(E / T) gets one writer).
-static __global__ void __launch_bounds__(256)
-msm_keys_kernel(const uint32_t* __restrict__ offsets, size_t K, uint32_t T_host, uint32_t* __restrict__ chunk_first,
-                uint32_t* __restrict__ hot_slot, uint32_t* __restrict__ tasks /* 2 words each: key, segment */,
-                uint32_t* task_count, uint32_t max_tasks) {
-  // long lists (degenerate columns: tens of thousands of chunks under one key) are filled by the whole block
-  __shared__ uint32_t long_key[256];
-  __shared__ uint32_t n_long;
-  const uint32_t T = msm_effective_t(offsets[K], T_host);
-  if (threadIdx.x == 0) n_long = 0;
-  __syncthreads();
-  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = key < K;
-  const uint32_t s = live ? offsets[key] : 0, e = live ? offsets[key + 1] : 0;
-  if (live) {
-    const uint32_t j0 = (s + T - 1) / T;
-    const uint64_t j1 = ((uint64_t)e + T - 1) / T;             // chunks j0 .. j1-1 start inside [s, e)
-    if (j1 > (uint64_t)j0 + 64) long_key[atomicAdd(&n_long, 1u)] = (uint32_t)key;
-    else
-      for (uint32_t j = j0; j < j1; j++) chunk_first[j] = (uint32_t)key;
-  }
-  __syncthreads();
-  for (uint32_t q = 0; q < n_long; q++) {
-    const uint32_t lk = long_key[q];
-    const uint32_t ls = offsets[lk], le = offsets[lk + 1];
-    const uint64_t j1 = ((uint64_t)le + T - 1) / T;
-    for (uint64_t j = (uint64_t)(ls + T - 1) / T + threadIdx.x; j < j1; j += blockDim.x) chunk_first[j] = lk;
-  }
-  if (!live) return;
-  uint32_t slot = MSM_NOT_HOT;
-  if (e > s) {
-    const uint32_t span = (e - 1) / T - s / T + 1;
-    if (span > MSM_HOT_SPAN) {
-      const uint32_t nseg = (span + MSM_HOT_SEG - 1) / MSM_HOT_SEG;
-      const uint32_t first = atomicAdd(task_count, nseg);
-      if (first + nseg <= max_tasks) {       // cannot fail by construction (see msm_workspace); stay in bounds anyway
-        slot = first;
-        for (uint32_t q = 0; q < nseg; q++) {
-          tasks[2 * (first + q)] = (uint32_t)key;
-          tasks[2 * (first + q) + 1] = q;
-        }
-      }
-    }
-  }
-  hot_slot[key] = slot;
 }
 
 // one wave per task = 16 quads (4 lanes per point, h2_curve_quad.hpp): quad g folds pieces g, g+16, ... of the
@@ -1006,14 +1039,6 @@ msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x MSM_FINA
     if (q < 3) fe_store<B>(out_jac + 6 * (size_t)col + 2 * q, v);
   }
   H2_STAMP(8);
-}
-
-constexpr uint32_t MSM_MAX_MULTI = 16;    // columns of a launch that may each bring their own bases
-struct MsmTableList {
-  const U128* t[MSM_MAX_MULTI];
-};
-static __global__ void msm_store_tables_kernel(MsmTableList L, const U128** dst, uint32_t m) {
-  if (threadIdx.x < m) dst[threadIdx.x] = L.t[threadIdx.x];
 }
 
 // ---- finish ---------------------------------------------------------------------------------------------
@@ -1506,6 +1531,24 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   // `offsets` which slots exist).
   if ((e = hipMemsetAsync(misc, 0, ws.zero_bytes, stream)) != hipSuccess) return e;
   uint32_t* tile_hist = (ws.staged || ws.sort2) ? (uint32_t*)(ws_base + ws.off_tile_hist) : nullptr;
+  // the keys pass (msm_keys_block): after the scan, beside or behind the scatter
+  const U128** d_tables = nullptr;
+  uint32_t log_b = 0;
+  MsmKeysArgs keys_args{};
+  keys_args.chunk_first = chunk_first;
+  keys_args.hot_slot = hot_slot;
+  keys_args.tasks = hot_tasks;
+  keys_args.task_count = misc;
+  keys_args.max_tasks = ws.max_tasks;
+  keys_args.T_host = ws.T;
+  if (per_column) {
+    d_tables = (const U128**)(misc + 16);                          // 128 bytes of the 256-byte misc block
+    keys_args.n_tables = (uint32_t)m;
+    keys_args.tables_dst = d_tables;
+    for (size_t j = 0; j < m; j++) keys_args.tables.t[j] = per_column[j];
+    while ((1u << log_b) < g.B) log_b++;
+  }
+  bool keys_merged = false;
   if (ws.sort2) {
     const Sort2Geom& s2 = ws.s2;
     const uint32_t H = s2.Hc * (uint32_t)m;
@@ -1537,25 +1580,24 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
       hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ws.nblk), dim3(256), 0, stream, counts, blocksums, offsets,
                          ws.K);
     }
-    if (ws.staged)
-      hipLaunchKernelGGL(msm_scatter_staged_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), ws.stage_lds, stream, d_scalars,
+    if (ws.staged) {
+      // the keys pass shared out over the scatter's blocks (at most one key per thread; the staging area holds its LDS
+      // at every bucket count this sort is chosen for -- the checks keep small geometries honest)
+      const size_t per = (ws.K + (size_t)tiles * m - 1) / ((size_t)tiles * m);
+      keys_merged = per <= MSM_SORT_THREADS && ws.stage_lds >= (size_t)4 * (MSM_SORT_THREADS + 1);
+      MsmKeysArgs ka = keys_args;
+      const uint32_t grid = sort_grid;
+      if (keys_merged) ka.keys_per_block = (uint32_t)per;
+      hipLaunchKernelGGL(msm_scatter_staged_kernel<CV>, dim3(grid), dim3(MSM_SORT_THREADS), ws.stage_lds, stream, d_scalars,
                          offsets, gcounts, tile_base, tile_hist, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles,
-                         (uint32_t)m, g, (uint32_t)(ws.tile * g.W));
-    else
+                         (uint32_t)m, g, (uint32_t)(ws.tile * g.W), ka);
+    } else
       hipLaunchKernelGGL(msm_scatter_kernel<CV>, dim3(sort_grid), dim3(MSM_SORT_THREADS), lds, stream, d_scalars, offsets,
                          gcounts, tile_base, sref, (uint32_t)n, col_stride, n_bases, ws.tile, tiles, (uint32_t)m, g);
   }
-  hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + 255) / 256)), dim3(256), 0, stream, offsets, ws.K, ws.T,
-                     chunk_first, hot_slot, hot_tasks, misc, ws.max_tasks);
-  const U128** d_tables = nullptr;
-  uint32_t log_b = 0;
-  if (per_column) {
-    MsmTableList L{};
-    for (size_t j = 0; j < m; j++) L.t[j] = per_column[j];
-    d_tables = (const U128**)(misc + 16);                          // 128 bytes of the 256-byte misc block
-    hipLaunchKernelGGL(msm_store_tables_kernel, dim3(1), dim3(64), 0, stream, L, d_tables, (uint32_t)m);
-    while ((1u << log_b) < g.B) log_b++;
-  }
+  if (!keys_merged)
+    hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((ws.K + MSM_KEYS_THREADS - 1) / MSM_KEYS_THREADS)), dim3(MSM_KEYS_THREADS), 0,
+                       stream, (const uint32_t*)offsets, ws.K, keys_args);
   // The roofline's start / stop events and the tail event (from the accumulate kernel's end on only small-grid kernels
   // run: other streams may fill the chip) ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): as separate
   // hipEventRecord calls each was a barrier packet of its own, ~6 us of stream time before and after the kernel
