@@ -97,6 +97,7 @@ int arena_acquire(Arena& a, size_t want, hipStream_t s) {
       a.bytes = 0;
       a.used = false;
     }
+    a.clean_bytes = 0;
     const size_t sz = want + (want >> 3);  // head-room so slightly larger calls do not reallocate
     hipError_t e = hipMalloc(&a.p, sz);
     if (e != hipSuccess) {
@@ -166,6 +167,7 @@ static int register_device(DevCtx& src, int curve, const void* d_affine, size_t 
     uint32_t bad = 0;
     // the table kernel's scratch (80 bytes per table entry) is the MSM workspace, idle while bases are being registered
     Arena& table_ws = src.msm_ws.of(src.stream);
+    table_ws.clean_bytes = 0;                      // the table kernel's scratch overwrites what an MSM left zeroed
     rc = arena_acquire(table_ws, be.table_bytes / 64 * MSM_TABLE_SCRATCH, src.stream);
     if (rc != H2_OK) return fail(rc);
     hipError_t e = hipMemsetAsync(d_bad, 0, 4, src.stream);
@@ -272,13 +274,20 @@ int msm_device_run(DevCtx& c, int curve, const BasesEntry& be, const void* d_sca
     }
     if (c.tail_wanted && !c.tail_event) H2_TRY(hipEventCreateWithFlags(&c.tail_event, hipEventDisableTiming));
     void* dst = (char*)d_out + j0 * out_sz;
+    // the previous launch sequence on this workspace left its counter region zero: no memset when this one's fits in it
+    const bool zeroed = !g_msm_guard && A.clean_bytes >= ws.zero_bytes && A.clean_off == ws.off_misc;
+    A.clean_bytes = 0;                             // (until this sequence is enqueued whole)
     hipError_t e = ops->msm_launch(table, per_column ? col_tables : nullptr, (uint32_t)be.n,
                                    (const char*)d_scalars + j0 * col_stride * 32, n, col_stride,
                                    mm, be.geom, (char*)A.p, ws, stream, ev0, ev1, (c.tail_wanted && !ev1) ? c.tail_event : nullptr,
-                                   affine_out ? nullptr : dst);
+                                   affine_out ? nullptr : dst, zeroed);
     c.tail_recorded = c.tail_wanted;
     c.tail_wait = ev1 ? ev1 : c.tail_event;
     if (e != hipSuccess) return dev_fail(e, "msm_launch");
+    if (!g_msm_guard) {
+      A.clean_off = ws.off_misc;
+      A.clean_bytes = ws.zero_bytes;
+    }
     if (g_msm_guard) {
       uint32_t* d_bad = nullptr;
       std::vector<uint32_t> bad(ws.n_regions, 0);
@@ -939,6 +948,7 @@ int h2_fft_group_device(h2_curve_t curve, void* d_points_jac, const uint64_t ome
   if (log_n == 0) return H2_OK;
   const CurveOps* ops = ops_of((int)curve);
   Arena& A = k.c->msm_ws.of(k.stream);
+  A.clean_bytes = 0;
   int rc = arena_acquire(A, ops->group_fft_scratch(log_n), k.stream);      // the MSM workspace, idle here
   if (rc != H2_OK) return rc;
   hipError_t e = ops->group_fft(d_points_jac, d_points_jac, A.p, omega, log_n, k.stream);

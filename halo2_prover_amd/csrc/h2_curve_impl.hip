@@ -38,9 +38,9 @@ hipError_t table_build(const void* d_bases, void* d_table, void* d_scratch, uint
 }
 hipError_t msm_launch_(const void* d_table, const void* const* per_column, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
                        const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s, hipEvent_t ev_start,
-                       hipEvent_t ev_stop, hipEvent_t ev_tail, void* d_out_jac) {
+                       hipEvent_t ev_stop, hipEvent_t ev_tail, void* d_out_jac, bool zeroed) {
   return msm_launch<CV>((const U128*)d_table, (const U128* const*)per_column, n_bases, (const U128*)d_scalars, n, col_stride, m, g, ws_base, ws, s, ev_start,
-                        ev_stop, ev_tail, (U128*)d_out_jac);
+                        ev_stop, ev_tail, (U128*)d_out_jac, zeroed);
 }
 hipError_t srs_powers(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s) {
   Fe<FS> sv;

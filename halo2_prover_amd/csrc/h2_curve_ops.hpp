@@ -25,7 +25,8 @@ struct CurveOps {
   hipError_t (*msm_launch)(const void* d_table, const void* const* per_column_tables, uint32_t n_bases, const void* d_scalars, size_t n, size_t col_stride, size_t m,
                            const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t s,
                            hipEvent_t ev_start, hipEvent_t ev_stop, hipEvent_t ev_tail,
-                           void* d_out_jac /* optional: m Jacobian results, written by the MSM's last kernel */);
+                           void* d_out_jac /* optional: m Jacobian results, written by the MSM's last kernel */,
+                           bool zeroed /* the workspace's zeroed region is zero already (left so by the previous launch sequence) */);
   hipError_t (*srs_powers)(void* d_out_affine, const uint64_t s_mont[4], uint32_t n, hipStream_t s);
   hipError_t (*fixed_base_mul)(void* d_out_affine, const void* d_scalars, uint32_t n, hipStream_t s);
   // `count` <= MSM_SMALL_MAX independent MSMs of a few dozen arbitrary points each (no table), side by side:

@@ -24,6 +24,9 @@ struct Arena {
   hipEvent_t ev = nullptr;        // recorded after the last enqueue that used the arena
   hipStream_t last = nullptr;
   bool used = false;
+  // MSM workspace: [clean_off, clean_off + clean_bytes) is zero when the work enqueued so far has run -- the previous MSM
+  // launch sequence zeroed its counter region again on its way out (msm_rowcol_kernel) -- so the next one skips its memset
+  size_t clean_off = 0, clean_bytes = 0;
 };
 
 // Scratch that a launch sequence owns from its first kernel to its last (the MSM workspace, the NTT's second buffer): one

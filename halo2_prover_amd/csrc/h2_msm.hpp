@@ -866,11 +866,19 @@ H2_HD bool msm_special_predoubled(uint32_t log_b, uint32_t lb) {
 template <class CV>
 __global__ void __launch_bounds__(256)
 msm_rowcol_kernel(const uint32_t* __restrict__ xsum, uint32_t* __restrict__ rc, uint32_t* __restrict__ done,
-                  uint32_t log_b, uint32_t lb) {
+                  uint32_t log_b, uint32_t lb, U128* zero_ptr = nullptr, uint32_t zero_u128 = 0) {
   __builtin_amdgcn_s_setprio(3);   // a dependent chain on a mostly idle SIMD: issue ahead of co-resident throughput kernels
   __shared__ uint32_t xw[3][XYZZ29_WORDS];
   const uint32_t col = blockIdx.y;
   if (blockIdx.x == 0 && threadIdx.x == 0) done[col] = 0;       // msm_final_kernel's arrival counter
+  // the launch sequence's zeroed region (misc + the sort's counters: every kernel that used it has finished) is left
+  // ZERO again for the next launch sequence on this workspace, which then needs no memset of its own (a fill kernel
+  // and its gaps: ~12 us of stream time in front of every MSM)
+  if (zero_ptr) {
+    const uint32_t nthr = gridDim.x * gridDim.y * blockDim.x;
+    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < zero_u128; i += nthr)
+      zero_ptr[i] = U128{0, 0, 0, 0};
+  }
   const uint32_t rows = 1u << (log_b - lb), cols = 1u << lb;
   const bool is_row = blockIdx.x < rows;
   const uint32_t first = is_row ? blockIdx.x * cols : blockIdx.x - rows;
@@ -1416,6 +1424,7 @@ inline const char* msm_check(const MsmWorkspace& ws, const MsmGeom& g, size_t n,
   MSM_REQUIRE(ws.K == m * (size_t)g.B && ws.E == m * (size_t)g.W * n);
   MSM_REQUIRE(ws.E < (1ull << 31) && ws.K < (1ull << 31));
   MSM_REQUIRE(bytes_at(ws.off_misc) >= ws.zero_bytes && ws.zero_bytes >= 256);
+  MSM_REQUIRE(ws.zero_bytes % 16 == 0 && ws.off_misc % 16 == 0 && ws.zero_bytes / 16 < (1ull << 32));   // re-zeroed by msm_rowcol_kernel
   MSM_REQUIRE(bytes_at(ws.off_offsets) >= (ws.K + 1) * 4);
   if (ws.sort2) {
     const Sort2Geom& s = ws.s2;
@@ -1506,7 +1515,9 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
                              uint32_t n_bases, const U128* d_scalars, size_t n, size_t col_stride,
                              size_t m, const MsmGeom& g, char* ws_base, const MsmWorkspace& ws, hipStream_t stream,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, hipEvent_t ev_tail = nullptr,
-                             U128* d_out_jac = nullptr /* m Jacobian points in the API's form, written by the last kernel */) {
+                             U128* d_out_jac = nullptr /* m Jacobian points in the API's form, written by the last kernel */,
+                             bool zeroed = false /* [off_misc, + zero_bytes) is zero already: the previous launch sequence on
+                                                    this workspace left it so (same off_misc, at least as many bytes) */) {
   uint32_t* counts = (uint32_t*)(ws_base + ws.off_counts);
   uint32_t* gcounts = (uint32_t*)(ws_base + ws.off_gcounts);
   uint32_t* offsets = (uint32_t*)(ws_base + ws.off_offsets);
@@ -1529,7 +1540,7 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   // one memset: misc (256 B) and the sort's counters behind it.  Nothing else needs clearing: every slot of bucket_sum /
   // head / tail that a later kernel reads has been written by the accumulate kernel (the fix-up decides from
   // `offsets` which slots exist).
-  if ((e = hipMemsetAsync(misc, 0, ws.zero_bytes, stream)) != hipSuccess) return e;
+  if (!zeroed && (e = hipMemsetAsync(misc, 0, ws.zero_bytes, stream)) != hipSuccess) return e;
   uint32_t* tile_hist = (ws.staged || ws.sort2) ? (uint32_t*)(ws_base + ws.off_tile_hist) : nullptr;
   // the keys pass (msm_keys_block): after the scan, beside or behind the scatter
   const U128** d_tables = nullptr;
@@ -1619,7 +1630,7 @@ inline hipError_t msm_launch(const U128* table, const U128* const* per_column /*
   uint32_t* part = (uint32_t*)(ws_base + ws.off_part);
   uint32_t* done = (uint32_t*)(ws_base + ws.off_done);
   hipLaunchKernelGGL(msm_rowcol_kernel<CV>, dim3(ws.rc, (unsigned)m), dim3(64 * msm_rowcol_waves(g.c - 1, ws.lb, m)), 0, stream,
-                     xsum, rc, done, g.c - 1, ws.lb);
+                     xsum, rc, done, g.c - 1, ws.lb, (U128*)misc, (uint32_t)(ws.zero_bytes / 16));
   hipLaunchKernelGGL(msm_final_kernel<CV>, dim3(msm_final_blocks(g.c - 1, ws.lb), (unsigned)m), dim3(64), 0, stream, rc, part,
                      done, tree2, d_out_jac, g.c - 1, ws.lb);
   return hipGetLastError();
