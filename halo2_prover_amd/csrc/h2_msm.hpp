@@ -946,7 +946,7 @@ __device__ __forceinline__ Xyzz29<CV> xyzz29_pick(uint32_t dig, const Xyzz29<CV>
 //     column family  the blocks behind them:        item lo = C_lo with multiplier lo + 1, lo < cols - 1   (< 2^lb)
 // multiplied two bits at a time (x, 2x, 3x, then per digit two doublings and one addition of the quad's own choice),
 // a shuffle tree over the wave's 16 quads, and the block that arrives last (a counter per column, zeroed by
-// msm_rowcol_kernel) adds the blocks' partials (two per quad, one more tree) and writes the column's MSM: XYZZ on the
+// msm_rowcol_kernel) adds the blocks' partials (one or more per quad, then a tree over the quads that hold one) and writes the column's MSM: XYZZ on the
 // working form to out[col] and, when out_jac is given, the Jacobian point in the API's form.
 //
 // The whole chain is ONE loop around one doubling and one addition (a little program counter decides what each step
@@ -972,8 +972,12 @@ msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x MSM_FINA
   const uint32_t* src = rc + XYZZ29_WORDS * ((size_t)col * (rows + cols));
   const uint32_t i = (fam ? blockIdx.x - nb_row : blockIdx.x) * 16 + quad;   // this quad's item
   const uint32_t n_weigh = 3 * ndig - 1;                         // double, add x, (double, double, add)*
-  const uint32_t n_more = nb > 16 ? (nb - 1) / 16 : 1;           // partials beyond the first per quad of the last block
-  const uint32_t n_tree = n_weigh + 4, n_all = n_tree + n_more + 4;
+  // the last block: quad q takes partials q, q + 16, ... (n_more further ones), then a tree over the quads that hold
+  // one -- three levels for the six blocks of a 2048-bucket column, not the full four
+  const uint32_t n_more = nb > 16 ? (nb - 1) / 16 : 0;
+  uint32_t lv2 = 0;
+  while ((1u << lv2) < min(nb, 16u)) lv2++;
+  const uint32_t n_tree = n_weigh + 4, n_all = n_tree + n_more + lv2;
   P x = P::identity(), x2 = P::identity(), x3 = P::identity();
   uint32_t k = 0;
   if (i < cnt) {
@@ -1004,7 +1008,7 @@ msm_final_kernel(const uint32_t* __restrict__ rc, uint32_t* part /* m x MSM_FINA
       const uint32_t j = quad + 16 * (pc - n_tree + 1);
       if (j < nb) o = xyzz29_load<CV>(part + XYZZ29_WORDS * ((size_t)col * MSM_FINAL_MAX_BLOCKS + j));
     } else {
-      const uint32_t d = 32u >> (pc - n_tree - n_more);
+      const uint32_t d = (2u << lv2) >> (pc - n_tree - n_more);       // 4 * 2^(lv2 - 1), ..., 8, 4 lanes
       o = xyzz_shfl_down(r, d);
       wanted = lane < d;
     }
