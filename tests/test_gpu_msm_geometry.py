@@ -174,3 +174,26 @@ def test_guard_mode_does_catch_an_overrun(h2, guarded):
         assert (launches, violations) == (1, 1) and "1 byte(s) behind the region" in first, first
     finally:
         bases.release()
+
+
+def test_launch_sequences_of_changing_shape_share_one_workspace(h2):
+    """without the guard mode's fill: a launch sequence leaves its counter region zero for the next one on the same
+    workspace, which skips its memset when its own region is no larger (Arena::clean_bytes).  Shapes whose layouts
+    differ -- more columns, fewer, another sort, another bucket count -- follow each other here; every result is checked"""
+    curve = "bn254"
+    nb = {12: bases_of(curve, 1 << 12, 0xC1), 13: bases_of(curve, 1 << 13, 0xC2), 18: bases_of(curve, 1 << 18, 0xC3)}
+    regs = {k: h2.Bases(curve, v) for k, v in nb.items()}
+    try:
+        plan = [(12, 1 << 12, 5), (12, 1 << 12, 2), (13, 1 << 13, 3), (12, 1 << 12, 5), (12, 3000, 1), (18, 1 << 18, 2),
+                (12, 1 << 12, 4), (13, (1 << 13) - 9, 7), (12, 1 << 12, 4), (18, 200000, 1), (12, 100, 3), (12, 1 << 12, 5)]
+        for step, (k, n, m) in enumerate(plan):
+            cols = [scalars(curve, n, 0x300 + 16 * step + j) for j in range(m)]
+            if m > 2:
+                cols[2][: n // 3] = 0
+            got = regs[k].msm_batch(cols)
+            for j in (0, m - 1):
+                want = O.to_affine(CID[curve], O.best_multiexp(CID[curve], cols[j], nb[k][:n], threads=8))
+                assert np.array_equal(got[j], want), (step, k, n, m, j)
+    finally:
+        for r in regs.values():
+            r.release()
