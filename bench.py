@@ -455,15 +455,22 @@ def main():
     # per-phase timing (outside the timed region; torch events see this stream because the library was
     # handed torch's current stream)
     phases_ms = {}
+    prof_alone = None
     for name, fn in (("msm", msm_phase), ("ntt", ntt_phase)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn()                                    # (scratch sized for this stream's calls before the clock starts)
         barrier()
+        if name == "msm" and phases:
+            L.h2_profile_enable(1)              # the accumulate kernel with nothing beside it (roofline: *_alone)
         e0.record()
         for _ in range(10):
             fn()
         e1.record()
         torch.cuda.synchronize()
+        if name == "msm" and phases:
+            prof_alone = h2lib.Profile()
+            h2lib.check(L.h2_profile_read(ctypes.byref(prof_alone)), "h2_profile_read")
+            L.h2_profile_enable(0)
         phases_ms[name] = round(e0.elapsed_time(e1) / 10, 4)
 
     # two steps in flight on the one GPU (sub-record; the line's value keeps one step at a time): even steps on the
@@ -560,7 +567,13 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_source,
                     "avg_kernel_ms": round(prof.kernel_ms / prof.launches, 5), "launches": int(prof.launches),
                     "algorithmic_bytes_per_launch": round(prof.algorithmic_bytes / prof.launches, 1),
-                    "note": "the contract's HBM fraction; the kernel is bound by the integer VALU, see modmul_frac"}
+                    "note": "the contract's HBM fraction; the kernel is bound by the integer VALU, see modmul_frac. "
+                            "Events over the timed region: in the step the first commit phase's accumulate kernel shares "
+                            "the chip with the advice columns' transforms (--schedule early_tail); *_alone = the same "
+                            "events over the MSM launch sequences run by themselves (phases_ms.msm)"}
+        if prof_alone is not None and prof_alone.launches:
+            roofline["avg_kernel_ms_alone"] = round(prof_alone.kernel_ms / prof_alone.launches, 5)
+            roofline["frac_alone"] = round(prof_alone.algorithmic_bytes / (prof_alone.kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
         if modmul:
             # one mixed addition (8M + 2S = 10 products, the formula's nominal count) per sorted entry; entries = terms
             # x windows.  Since round 3 the kernel executes fewer multiply-adds than ten full products: the two squarings
@@ -572,6 +585,10 @@ def main():
             roofline["modmul_per_s"] = mm / (prof.kernel_ms * 1e-3)
             roofline["modmul_frac"] = round(roofline["modmul_per_s"] / modmul["at_3_waves_per_simd"], 4)
             roofline["modmul_frac_executed"] = round(roofline["modmul_frac"] * PRODUCT_EQUIVALENTS_PER_ADD / 10.0, 4)
+            if prof_alone is not None and prof_alone.launches:
+                mm_alone = prof_alone.algorithmic_bytes / 96.0 * plan["windows"] * 10 / (prof_alone.kernel_ms * 1e-3)
+                roofline["modmul_frac_alone"] = round(mm_alone / modmul["at_3_waves_per_simd"], 4)
+                roofline["modmul_frac_executed_alone"] = round(roofline["modmul_frac_alone"] * PRODUCT_EQUIVALENTS_PER_ADD / 10.0, 4)
             if "msm" in phases_ms and n_msm:
                 whole = (n_msm * n * plan["windows"] * 10) / (phases_ms["msm"] * 1e-3)     # this rank's own 16 columns
                 roofline["msm_phase_modmul_per_s"] = whole
