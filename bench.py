@@ -598,10 +598,9 @@ def main():
                 roofline["msm_phase_modmul_frac"] = round(whole / modmul["at_8_waves_per_simd"], 4)
 
     def sub(fn, *a):
-        """a sub-record on ONE rank (no collective inside): its failure is recorded in the line, it does not take the
-        measured values with it"""
-        if world > 1:
-            return fn(*a)
+        """a sub-record's failure is recorded in the line, it does not take the measured values with it.  (With several
+        ranks this holds for failures every rank meets at the same place; a rank that fails alone still leaves the others
+        in the sub-record's next collective.)"""
         try:
             return fn(*a)
         except Exception as exc:  # noqa: BLE001
@@ -621,7 +620,7 @@ def main():
         torch.cuda.empty_cache()
         extras["headline_msm_2e20"] = sub(headline_msm, args, 20, make_srs, world, rank, dev, stream, barrier, modmul, p, multi)
         if multi:
-            extras["config5"] = config5(args, make_srs, world, rank, dev, stream, barrier, p, gen, two_adicity, R)
+            extras["config5"] = sub(config5, args, make_srs, world, rank, dev, stream, barrier, p, gen, two_adicity, R)
         if world == 1 and not multi:
             # sub-records on one GPU: the pinned curve, and the host-pointer route
             if args.curve != "bn254":
@@ -633,7 +632,7 @@ def main():
     # ran (the C++ prover shards its commit phases over the contexts of h2_init_devices, not over ranks)
     proof_gen_multi = None
     if not args.no_proof and args.workload == "poseidon" and rank == 0:
-        proof_gen = sub(proof_generation, k) if world == 1 else proof_generation(k)
+        proof_gen = sub(proof_generation, k)
     if not args.no_proof and args.workload == "poseidon" and world > 1 and ndev >= world:
         # the N-GPU proof: ONE process with N contexts (h2_init_devices), started by rank 0 while the other ranks wait at
         # the barrier below with their GPUs idle; its commit phases are split by point range over the N GPUs
